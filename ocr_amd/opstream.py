@@ -1,0 +1,286 @@
+"""Op streams: OCR programs as data (format: include/ocr_opstream.h), and the synthetic
+DAG generators of SURVEY.md s8(d).
+
+An :class:`OpStream` is the list of public OCR API calls a ``mainEdt`` would issue
+(``ocrEventCreate``/``ocrDbCreate``/``ocrEdtCreate``/``ocrAddDependence``/
+``ocrEventSatisfySlot``, ocr/inc/ocr-edt.h:63-347, ocr/inc/ocr-db.h:78) plus a per-EDT
+script of the satisfies its body performs.  It is the one input every executor sees:
+the reference runtime (oracle/ocr_replay.c), the CPU restatement (oracle/engine_ref.c)
+and the MI355X engine (ocr_amd.engine through include/ocrgpu.h).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+MAGIC = 0x003153504F52434F
+RES_MAGIC = 0x0031534552524F43
+
+OP_EVT_CREATE, OP_DB_CREATE, OP_EDT_CREATE, OP_ADD_DEP, OP_SATISFY, OP_EVT_DESTROY = 1, 2, 3, 4, 5, 6
+REF_NULL, REF_EDT, REF_EVT, REF_DB, REF_OUTEVT, REF_OUTDB, REF_DEPV, REF_UNINIT = range(8)
+BODY_NOP, BODY_HASH, BODY_FWD0 = 0, 1, 2
+BODY_F_OUTEVT, BODY_F_SINK = 0x100, 0x200
+EVT_ONCE, EVT_IDEM, EVT_STICKY, EVT_LATCH, EVT_COUNTED, EVT_CHANNEL = 1, 2, 3, 4, 5, 6
+LATCH_DECR, LATCH_INCR = 0, 1
+MODE_NULL, MODE_CONST, MODE_RW, MODE_EW, MODE_RO = 0, 1, 2, 4, 8
+EVS_DESTROYED, EVS_LIVE_UNSAT, EVS_LIVE_SAT, EVS_ABSENT = 0, 1, 2, 3
+
+HDR_DT = np.dtype([("magic", "<u8"), ("n_edt", "<u4"), ("n_evt", "<u4"), ("n_db", "<u4"),
+                   ("n_main", "<u4"), ("n_script", "<u4"), ("sink_edt", "<u4"), ("pad", "<u4", 8)])
+EDT_DT = np.dtype([("depc", "<u4"), ("body", "<u4"), ("script_begin", "<u4"), ("script_len", "<u4")])
+EVT_DT = np.dtype([("kind", "<u4"), ("arg", "<i4")])
+OP_DT = np.dtype([("op", "u1"), ("mode", "u1"), ("pad", "<u2"), ("slot", "<u4"), ("a", "<u8"), ("b", "<u8")])
+RES_HDR_DT = np.dtype([("magic", "<u8"), ("n_edt", "<u4"), ("n_evt_total", "<u4"), ("n_db_total", "<u4"),
+                       ("n_fired", "<u4"), ("pad", "<u4", 10)])
+assert HDR_DT.itemsize == 64 and EDT_DT.itemsize == 16 and OP_DT.itemsize == 24 and RES_HDR_DT.itemsize == 64
+
+
+def ref(cls, idx=0):
+    """Object reference (class in the top byte). Works on ints and numpy arrays."""
+    if isinstance(idx, np.ndarray):
+        return (np.uint64(cls) << np.uint64(56)) | idx.astype(np.uint64)
+    return (int(cls) << 56) | int(idx)
+
+
+def ref_cls(r):
+    return r >> 56 if not isinstance(r, np.ndarray) else (r >> np.uint64(56)).astype(np.uint32)
+
+
+def ref_idx(r):
+    m = 0x00FFFFFFFFFFFFFF
+    return r & m if not isinstance(r, np.ndarray) else (r & np.uint64(m))
+
+
+def make_ops(op, a, b=0, slot=0, mode=0):
+    """Build an OP_DT array from scalars/arrays (broadcast against ``a``)."""
+    a = np.atleast_1d(np.asarray(a, dtype=np.uint64))
+    out = np.zeros(a.shape[0], dtype=OP_DT)
+    out["op"] = op
+    out["a"] = a
+    out["b"] = b
+    out["slot"] = slot
+    out["mode"] = mode
+    return out
+
+
+class OpStream:
+    """SoA container for one program. ``main`` and ``script`` are OP_DT arrays."""
+
+    def __init__(self, edt, evt, db_init, main, script, sink_edt, name="", meta=None):
+        self.edt = np.ascontiguousarray(edt, dtype=EDT_DT)
+        self.evt = np.ascontiguousarray(evt, dtype=EVT_DT)
+        self.db_init = np.ascontiguousarray(db_init, dtype=np.uint64)
+        self.main = np.ascontiguousarray(main, dtype=OP_DT)
+        self.script = np.ascontiguousarray(script, dtype=OP_DT)
+        self.sink_edt = int(sink_edt)
+        self.name = name
+        self.meta = dict(meta or {})
+
+    n_edt = property(lambda s: len(s.edt))
+    n_evt = property(lambda s: len(s.evt))
+    n_db = property(lambda s: len(s.db_init))
+    n_evt_total = property(lambda s: len(s.evt) + len(s.edt))
+    n_db_total = property(lambda s: len(s.db_init) + len(s.edt))
+
+    def n_satisfy_ops(self):
+        """Dependence satisfactions a full resolve applies (SURVEY.md s8d metric numerator):
+        every (dst,slot) satisfy applied to an EDT pre-slot or an event pre-slot."""
+        return self.meta.get("n_satisfactions")
+
+    def to_file(self, path):
+        hdr = np.zeros(1, dtype=HDR_DT)
+        hdr["magic"] = MAGIC
+        hdr["n_edt"], hdr["n_evt"], hdr["n_db"] = self.n_edt, self.n_evt, self.n_db
+        hdr["n_main"], hdr["n_script"], hdr["sink_edt"] = len(self.main), len(self.script), self.sink_edt
+        with open(path, "wb") as f:
+            for arr in (hdr, self.edt, self.evt, self.db_init, self.main, self.script):
+                f.write(arr.tobytes())
+
+    @classmethod
+    def from_file(cls, path):
+        buf = np.fromfile(path, dtype=np.uint8)
+        hdr = buf[:64].view(HDR_DT)[0]
+        assert int(hdr["magic"]) == MAGIC, "not an op-stream file"
+        off = 64
+        out = []
+        for dt, n in ((EDT_DT, hdr["n_edt"]), (EVT_DT, hdr["n_evt"]), (np.dtype("<u8"), hdr["n_db"]),
+                      (OP_DT, hdr["n_main"]), (OP_DT, hdr["n_script"])):
+            nb = int(n) * dt.itemsize
+            out.append(buf[off:off + nb].view(dt).copy())
+            off += nb
+        return cls(out[0], out[1], out[2], out[3], out[4], int(hdr["sink_edt"]))
+
+
+class Result:
+    """The parity record (include/ocr_opstream.h): levels, HASH values, event states, DB values."""
+
+    def __init__(self, level, val, evt_state, db_val):
+        self.level = np.asarray(level, dtype=np.int32)
+        self.val = np.asarray(val, dtype=np.uint64)
+        self.evt_state = np.asarray(evt_state, dtype=np.uint64)
+        self.db_val = np.asarray(db_val, dtype=np.uint64)
+
+    @property
+    def n_fired(self):
+        return int((self.level >= 0).sum())
+
+    def to_file(self, path):
+        hdr = np.zeros(1, dtype=RES_HDR_DT)
+        hdr["magic"] = RES_MAGIC
+        hdr["n_edt"], hdr["n_evt_total"], hdr["n_db_total"] = len(self.level), len(self.evt_state), len(self.db_val)
+        hdr["n_fired"] = self.n_fired
+        with open(path, "wb") as f:
+            for arr in (hdr, self.level, self.val, self.evt_state, self.db_val):
+                f.write(np.ascontiguousarray(arr).tobytes())
+
+    @classmethod
+    def from_file(cls, path):
+        buf = np.fromfile(path, dtype=np.uint8)
+        hdr = buf[:64].view(RES_HDR_DT)[0]
+        assert int(hdr["magic"]) == RES_MAGIC, "not a result file"
+        ne, nv, nd = int(hdr["n_edt"]), int(hdr["n_evt_total"]), int(hdr["n_db_total"])
+        off = 64
+        level = buf[off:off + 4 * ne].view("<i4").copy(); off += 4 * ne
+        val = buf[off:off + 8 * ne].view("<u8").copy(); off += 8 * ne
+        evs = buf[off:off + 8 * nv].view("<u8").copy(); off += 8 * nv
+        dbv = buf[off:off + 8 * nd].view("<u8").copy()
+        return cls(level, val, evs, dbv)
+
+    def level_hashes(self):
+        """64-bit FNV-1a over the sorted fired-id set of each level (the per-level parity key)."""
+        fired = np.nonzero(self.level >= 0)[0]
+        out = {}
+        if len(fired) == 0:
+            return out
+        lv = self.level[fired]
+        order = np.lexsort((fired, lv))
+        fired, lv = fired[order], lv[order]
+        bounds = np.nonzero(np.diff(lv))[0] + 1
+        for ids, l in zip(np.split(fired, bounds), lv[np.r_[0, bounds]]):
+            out[int(l)] = (len(ids), fnv1a64(ids.astype("<u4").tobytes()))
+        return out
+
+    def digest(self):
+        """One 64-bit digest of the whole record (checksum of checksums)."""
+        h = 0xCBF29CE484222325
+        for arr in (self.level, self.val, self.evt_state, self.db_val):
+            h ^= fnv1a64(np.ascontiguousarray(arr).tobytes())
+            h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    def diff(self, other):
+        """Human-readable list of mismatches against another Result ([] == bit-exact)."""
+        msgs = []
+        for nm in ("level", "val", "evt_state", "db_val"):
+            a, b = getattr(self, nm), getattr(other, nm)
+            if a.shape != b.shape:
+                msgs.append(f"{nm}: shape {a.shape} vs {b.shape}")
+                continue
+            bad = np.nonzero(a != b)[0]
+            if len(bad):
+                i = int(bad[0])
+                msgs.append(f"{nm}: {len(bad)} mismatches, first at [{i}]: {int(a[i])} vs {int(b[i])}")
+        return msgs
+
+
+def fnv1a64(data: bytes) -> int:
+    """FNV-1a, vectorised by 8-byte words for speed: digest of a byte string.
+
+    (Not the byte-serial FNV: the word-wise fold below is what every checker here uses.)"""
+    pad = (-len(data)) % 8
+    w = np.frombuffer(data + b"\0" * pad, dtype="<u8")
+    if len(w) == 0:
+        return 0xCBF29CE484222325
+    # position-dependent multiply then xor-fold: order sensitive, O(n) in numpy
+    idx = np.arange(1, len(w) + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (w + idx * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return int(np.bitwise_xor.reduce(z)) ^ (len(data) * 0x100000001B3 & 0xFFFFFFFFFFFFFFFF)
+
+
+# ----------------------------------------------------------------------------------------------
+# SplitMix64, counter-based (vectorised): element i of stream `seed` is mix(seed + (i+1)*golden)
+# ----------------------------------------------------------------------------------------------
+def splitmix64(seed: int, n: int, offset: int = 0) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        i = np.arange(offset + 1, offset + n + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+SEED_BASE = 0x0C5200000000  # seed = 0x0C5200000000 + config#
+
+
+def layered_dag(n_edt: int, width: int, seed: int = SEED_BASE + 2, name=None) -> OpStream:
+    """BASELINE config 2: layered random DAG with ONCE output events.
+
+    ``n_edt`` EDTs in ``n_edt/width`` layers of ``width``.  An EDT in layer l>0 has
+    depc = 1 + popcount(6 random bits) (1..7, mean 4) sources drawn uniformly from layer
+    l-1, each dependence an ``ocrAddDependence(outputEvent(src), edt, slot, RO)``.  Every
+    EDT has a HASH body and one ONCE output event carrying its output datablock.  Layer 0
+    hangs off one ONCE ``start`` event (satisfied by the last main op), because a depc==0
+    EDT fires inside ocrEdtCreate (hc-task.c:1129-1134) and its output event would be
+    satisfied-and-destroyed before its consumers register (hc-event.c:450-464,1078-1083).
+    EDTs nobody consumes DECR one LATCH (initial count = their number) whose post-slot
+    fires the sink EDT #n_edt, which calls ocrShutdown (SURVEY.md s8a rule 10).
+    """
+    assert n_edt % width == 0 and n_edt >= width
+    n_layers = n_edt // width
+    N = n_edt
+    depc = np.ones(N, dtype=np.uint32)
+    if n_layers > 1:
+        bits = splitmix64(seed, N - width) & np.uint64(0x3F)
+        pop = np.zeros(N - width, dtype=np.uint32)
+        for k in range(6):
+            pop += ((bits >> np.uint64(k)) & np.uint64(1)).astype(np.uint32)
+        depc[width:] = 1 + pop
+    slot_base = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(depc, out=slot_base[1:])
+    n_edges = int(slot_base[N]) - width  # layer-0 slots hang off `start`
+    # edge list for layers >= 1
+    dst = np.repeat(np.arange(width, N, dtype=np.int64), depc[width:])
+    slot = (np.arange(n_edges, dtype=np.int64) - (slot_base[dst] - width)).astype(np.uint32)
+    layer_of_dst = dst // width
+    r = splitmix64(seed ^ 0xA5A5A5A5, n_edges)
+    src = (layer_of_dst - 1) * width + (r % np.uint64(width)).astype(np.int64)
+    consumed = np.zeros(N, dtype=bool)
+    consumed[src] = True
+    leaves = np.nonzero(~consumed)[0]
+    n_leaves = len(leaves)
+
+    EV_START, EV_LATCH = 0, 1
+    sink = N
+    edt = np.zeros(N + 1, dtype=EDT_DT)
+    edt["depc"][:N] = depc
+    edt["body"][:N] = BODY_HASH | BODY_F_OUTEVT
+    edt["depc"][N] = 1
+    edt["body"][N] = BODY_NOP | BODY_F_SINK
+    # scripts: leaves DECR the latch
+    script = make_ops(OP_SATISFY, np.full(n_leaves, ref(REF_EVT, EV_LATCH), dtype=np.uint64), b=0, slot=LATCH_DECR)
+    edt["script_begin"][leaves] = np.arange(n_leaves, dtype=np.uint32)
+    edt["script_len"][leaves] = 1
+    evt = np.zeros(2, dtype=EVT_DT)
+    evt["kind"] = [EVT_ONCE, EVT_LATCH]
+    evt["arg"] = [0, n_leaves]
+
+    main = np.concatenate([
+        make_ops(OP_EVT_CREATE, [EV_START, EV_LATCH]),
+        make_ops(OP_EDT_CREATE, np.arange(N + 1)),
+        make_ops(OP_ADD_DEP, ref(REF_OUTEVT, src), b=ref(REF_EDT, dst), slot=slot, mode=MODE_RO),
+        make_ops(OP_ADD_DEP, np.full(width, ref(REF_EVT, EV_START), dtype=np.uint64),
+                 b=ref(REF_EDT, np.arange(width)), slot=0, mode=MODE_NULL),
+        make_ops(OP_ADD_DEP, [ref(REF_EVT, EV_LATCH)], b=ref(REF_EDT, sink), slot=0, mode=MODE_NULL),
+        make_ops(OP_SATISFY, [ref(REF_EVT, EV_START)], b=0, slot=0),
+    ])
+    # Metric numerator ("E"): satisfies applied to EDT pre-slots (sum of depc
+    # over fired EDTs, sink included) + satisfies applied to LATCH pre-slots.  The 1:1
+    # epilogue satisfy of each EDT's own output event is NOT counted (conservative).
+    n_sat = int(slot_base[N]) + 1 + n_leaves
+    meta = dict(kind="layered", n_layers=n_layers, width=width, n_edges=n_edges + width + 1,
+                n_leaves=n_leaves, n_satisfactions=n_sat, seed=seed)
+    return OpStream(edt, evt, np.zeros(0, dtype=np.uint64), main, script, sink,
+                    name=name or f"layered_N{N}_W{width}", meta=meta)

@@ -1,0 +1,292 @@
+/*
+ * ocr_replay.c -- TEST INFRASTRUCTURE (the checker), never shipped or measured as product.
+ *
+ * A plain OCR program that replays an op stream (include/ocr_opstream.h) through the
+ * PUBLIC OCR API of the *reference* runtime (linked against oracle/_ref/libocr_x86_*.a,
+ * which oracle/Makefile.ref compiles from /root/reference/ocr/src where it lies).  Every
+ * dependence decision -- which EDTs fire, what guid each pre-slot receives, which events
+ * self-destruct, what a latch counter ends at -- is taken by the reference code:
+ *   ocrEdtCreate      ocr/src/api/ocr-edt.c:295   -> newTaskHc        hc-task.c:871
+ *   ocrAddDependence  ocr/src/api/ocr-edt.c:551   -> hc-policy.c:2775
+ *   ocrEventSatisfySlot ocr-edt.c:127             -> hc-policy.c:3203 -> hc-event.c:437/726/597/620
+ *   satisfyTaskHc     hc-task.c:1216, taskExecute hc-task.c:1864, taskEpilogue :1707
+ * This file only (a) turns ops into API calls, (b) runs the EDT bodies the stream names,
+ * (c) keeps a Lamport clock per event so "topological level" is well defined for pure
+ * control dependences (the public API gives a body no way to see who triggered it), and
+ * (d) at the sink EDT dumps the parity record: per-EDT level + HASH value, final event
+ * states (read from the reference's own metadata through its GUID provider; needs the
+ * COUNTED_MAP provider, where a destroyed guid no longer resolves,
+ * counted-map-guid.c:394-406,540-548), and datablock values.
+ *
+ * usage: ocr_replay -ocr:cfg <cfg> <ops-file> <result-file|->
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <sys/time.h>
+#include "ocr.h"
+/* reference internals, only for the final-state peek in dump_event_state() */
+#include "ocr-policy-domain.h"
+#include "ocr-guid.h"
+#include "ocr-sal.h"
+#include "event/hc/hc-event.h"
+#include "ocr_opstream.h"
+
+#define CLK_UNSET LLONG_MIN
+#define CLK_MAIN  (-1LL)
+
+static struct {
+    ocrops_hdr_t hdr;
+    ocrops_edt_t *edt; ocrops_evt_t *evt; uint64_t *db_init; ocrops_op_t *main_ops, *script;
+    uint32_t n_evt_total, n_db_total;
+    ocrGuid_t *edt_guid, *evt_guid, *db_guid; uint64_t **db_ptr;
+    /* static structure for the Lamport harness */
+    uint64_t *slot_base;     /* [n_edt+1] */
+    uint64_t *slot_src;      /* [sum depc] source ref of each EDT pre-slot (0 = none/NULL/DB) */
+    uint32_t *feed_ptr, *feed_idx; /* CSR: events feeding event x through ocrAddDependence(evt,evt) */
+    volatile long long *clk; /* [n_evt_total] */
+    int32_t *level; uint64_t *val;
+    volatile uint32_t n_fired;
+    const char *res_path; int guid_is_map;
+    struct timeval t0; int t0_set;
+    uint64_t n_sat_edges;
+} G;
+
+static double now_minus(struct timeval *a) {
+    struct timeval b; gettimeofday(&b, NULL);
+    return (b.tv_sec - a->tv_sec) + 1e-6 * (b.tv_usec - a->tv_usec);
+}
+
+static uint32_t evt_index(uint64_t r) { /* unified event index of an EVT / OUTEVT ref */
+    return OCRREF_CLS(r) == OCRREF_EVT ? (uint32_t)OCRREF_IDX(r) : G.hdr.n_evt + (uint32_t)OCRREF_IDX(r);
+}
+static uint32_t evt_kind(uint32_t x) { return x < G.hdr.n_evt ? G.evt[x].kind : OCREVT_ONCE; }
+
+static ocrGuid_t ref_guid(uint64_t r, uint32_t self, ocrEdtDep_t *depv) {
+    switch (OCRREF_CLS(r)) {
+    case OCRREF_NULL:   return NULL_GUID;
+    case OCRREF_EDT:    return G.edt_guid[OCRREF_IDX(r)];
+    case OCRREF_EVT:    return G.evt_guid[OCRREF_IDX(r)];
+    case OCRREF_OUTEVT: return G.evt_guid[G.hdr.n_evt + OCRREF_IDX(r)];
+    case OCRREF_DB:     return G.db_guid[OCRREF_IDX(r)];
+    case OCRREF_OUTDB:  return G.db_guid[G.hdr.n_db + OCRREF_IDX(r)];
+    case OCRREF_DEPV:   return depv[OCRREF_IDX(r)].guid;
+    case OCRREF_UNINIT: return UNINITIALIZED_GUID;
+    }
+    (void)self; return ERROR_GUID;
+}
+
+/* ---- Lamport harness: level of the EDT whose action made event x fire ---- */
+static void clk_note(uint32_t x, long long lvl) {
+    volatile long long *p = &G.clk[x];
+    if (evt_kind(x) == OCREVT_LATCH) { /* fires on the LAST op: max over contributors */
+        long long o = *p;
+        while (o < lvl && !__sync_bool_compare_and_swap(p, o, lvl)) o = *p;
+    } else { /* ONCE / IDEM / STICKY: the first satisfy is the one that fires */
+        __sync_bool_compare_and_swap(p, CLK_UNSET, lvl);
+    }
+}
+static long long clk_resolve(uint32_t x) {
+    long long m = G.clk[x];
+    if (evt_kind(x) != OCREVT_LATCH && m != CLK_UNSET) return m;
+    for (uint32_t k = G.feed_ptr[x]; k < G.feed_ptr[x + 1]; ++k) {
+        long long f = clk_resolve(G.feed_idx[k]);
+        if (f > m) m = f;
+    }
+    return m;
+}
+
+static void do_satisfy(const ocrops_op_t *op, uint32_t self, long long lvl, ocrEdtDep_t *depv) {
+    ocrGuid_t dst = ref_guid(op->a, self, depv), payload = ref_guid(op->b, self, depv);
+    uint32_t c = OCRREF_CLS(op->a);
+    if (c == OCRREF_EVT || c == OCRREF_OUTEVT) clk_note(evt_index(op->a), lvl);
+    ocrEventSatisfySlot(dst, payload, op->slot);
+}
+
+static void dump_results(void);
+
+static ocrGuid_t bodyEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) {
+    uint32_t id = (uint32_t)paramv[0];
+    const ocrops_edt_t *e = &G.edt[id];
+    /* level: 1 + max over the pre-slots of the clock of whatever satisfied it */
+    long long lvl = 0;
+    uint64_t v = ocrops_hash_init(id);
+    for (u32 i = 0; i < depc; ++i) {
+        uint64_t s = G.slot_src[G.slot_base[id] + i];
+        uint32_t c = OCRREF_CLS(s);
+        if (c == OCRREF_EVT || c == OCRREF_OUTEVT) {
+            long long f = clk_resolve(evt_index(s));
+            if (f == CLK_UNSET) { fprintf(stderr, "replay: EDT %u slot %u fired before its source\n", id, i); abort(); }
+            if (f + 1 > lvl) lvl = f + 1;
+        }
+        uint64_t pv = 0, did = 0;
+        if (depv[i].ptr != NULL) { pv = ((uint64_t *)depv[i].ptr)[0]; did = ((uint64_t *)depv[i].ptr)[1] + 1; }
+        v = ocrops_hash_step(v, i, pv, did);
+    }
+    ocrGuid_t ret = NULL_GUID;
+    switch (OCRBODY_KIND(e->body)) {
+    case OCRBODY_HASH: {
+        uint64_t *p; ocrGuid_t g;
+        ocrDbCreate(&g, (void **)&p, 16, 0, NULL_HINT, NO_ALLOC);
+        p[0] = v; p[1] = G.hdr.n_db + id;
+        G.db_guid[G.hdr.n_db + id] = g; G.db_ptr[G.hdr.n_db + id] = p;
+        ocrDbRelease(g);
+        ret = g;
+    } break;
+    case OCRBODY_FWD0: ret = depc ? depv[0].guid : NULL_GUID; break;
+    default: break;
+    }
+    for (uint32_t k = 0; k < e->script_len; ++k) {
+        const ocrops_op_t *op = &G.script[e->script_begin + k];
+        if (op->op == OCROP_SATISFY) do_satisfy(op, id, lvl, depv);
+        else if (op->op == OCROP_EVT_DESTROY) ocrEventDestroy(ref_guid(op->a, id, depv));
+    }
+    if (e->body & OCRBODY_F_OUTEVT) clk_note(G.hdr.n_evt + id, lvl); /* epilogue satisfies it, hc-task.c:1813-1830 */
+    G.level[id] = (int32_t)lvl; G.val[id] = v;
+    __sync_fetch_and_add(&G.n_fired, 1);
+    if (e->body & OCRBODY_F_SINK) {
+        double dt = G.t0_set ? now_minus(&G.t0) : 0.0;
+        dump_results();
+        printf("REPLAY fired=%u edges=%llu resolve_s=%.6f sat_per_s=%.1f\n", G.n_fired,
+               (unsigned long long)G.n_sat_edges, dt, dt > 0 ? G.n_sat_edges / dt : 0.0);
+        fflush(stdout);
+        ocrShutdown();
+    }
+    return ret;
+}
+
+/* final state of one event, read from the reference's metadata (hc-event.h:61-86) */
+static uint64_t dump_event_state(ocrPolicyDomain_t *pd, uint32_t x) {
+    ocrGuid_t g = G.evt_guid[x];
+    if (ocrGuidIsNull(g)) return OCREVS(OCREVS_ABSENT, 0);
+    if (!G.guid_is_map) return OCREVS(OCREVS_ABSENT, 0);
+    u64 val = 0; ocrGuidKind kind;
+    ocrGuidProvider_t *gp = pd->guidProviders[0];
+    gp->fcts.getVal(gp, g, &val, &kind, MD_LOCAL, NULL);
+    if (val == 0) return OCREVS(OCREVS_DESTROYED, 0);
+    uint32_t k = evt_kind(x);
+    if (k == OCREVT_LATCH) return OCREVS(OCREVS_LIVE_UNSAT, (uint32_t)((ocrEventHcLatch_t *)val)->counter);
+    if (k == OCREVT_ONCE) return OCREVS(OCREVS_LIVE_UNSAT, 0);
+    ocrGuid_t d = ((ocrEventHcPersist_t *)val)->data; /* UNINITIALIZED_GUID until satisfied, hc-event.c:1616 */
+    if (ocrGuidIsUninitialized(d)) return OCREVS(OCREVS_LIVE_UNSAT, 0);
+    uint32_t did = 0;
+    if (!ocrGuidIsNull(d))
+        for (uint32_t i = 0; i < G.n_db_total; ++i) if (ocrGuidIsEq(G.db_guid[i], d)) { did = i + 1; break; }
+    return OCREVS(OCREVS_LIVE_SAT, did);
+}
+
+static void dump_results(void) {
+    if (!G.res_path || !strcmp(G.res_path, "-")) return;
+    ocrPolicyDomain_t *pd = NULL; getCurrentEnv(&pd, NULL, NULL, NULL);
+    FILE *f = fopen(G.res_path, "wb");
+    if (!f) { perror("result file"); abort(); }
+    ocrres_hdr_t h; memset(&h, 0, sizeof h);
+    h.magic = OCRRES_MAGIC; h.n_edt = G.hdr.n_edt; h.n_evt_total = G.n_evt_total; h.n_db_total = G.n_db_total;
+    h.n_fired = G.n_fired;
+    fwrite(&h, sizeof h, 1, f);
+    fwrite(G.level, 4, G.hdr.n_edt, f);
+    fwrite(G.val, 8, G.hdr.n_edt, f);
+    for (uint32_t x = 0; x < G.n_evt_total; ++x) { uint64_t s = dump_event_state(pd, x); fwrite(&s, 8, 1, f); }
+    for (uint32_t d = 0; d < G.n_db_total; ++d) { uint64_t v = G.db_ptr[d] ? G.db_ptr[d][0] : 0; fwrite(&v, 8, 1, f); }
+    fclose(f);
+}
+
+static void load_stream(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); abort(); }
+    if (fread(&G.hdr, sizeof G.hdr, 1, f) != 1 || G.hdr.magic != OCROPS_MAGIC) { fprintf(stderr, "bad op stream\n"); abort(); }
+#define RD(ptr, n, T) do { ptr = (T *)calloc((n) ? (n) : 1, sizeof(T)); if ((n) && fread(ptr, sizeof(T), (n), f) != (n)) { fprintf(stderr, "short read\n"); abort(); } } while (0)
+    RD(G.edt, G.hdr.n_edt, ocrops_edt_t); RD(G.evt, G.hdr.n_evt, ocrops_evt_t); RD(G.db_init, G.hdr.n_db, uint64_t);
+    RD(G.main_ops, G.hdr.n_main, ocrops_op_t); RD(G.script, G.hdr.n_script, ocrops_op_t);
+    fclose(f);
+    G.n_evt_total = G.hdr.n_evt + G.hdr.n_edt; G.n_db_total = G.hdr.n_db + G.hdr.n_edt;
+    G.edt_guid = calloc(G.hdr.n_edt + 1, sizeof(ocrGuid_t));
+    G.evt_guid = calloc(G.n_evt_total + 1, sizeof(ocrGuid_t));
+    G.db_guid = calloc(G.n_db_total + 1, sizeof(ocrGuid_t));
+    G.db_ptr = calloc(G.n_db_total + 1, sizeof(uint64_t *));
+    G.level = malloc(4 * (G.hdr.n_edt + 1)); memset(G.level, 0xFF, 4 * (G.hdr.n_edt + 1));
+    G.val = calloc(G.hdr.n_edt + 1, 8);
+    G.clk = malloc(8 * (G.n_evt_total + 1));
+    for (uint32_t i = 0; i < G.n_evt_total; ++i) G.clk[i] = CLK_UNSET;
+    G.slot_base = calloc(G.hdr.n_edt + 1, 8);
+    for (uint32_t i = 0; i < G.hdr.n_edt; ++i) G.slot_base[i + 1] = G.slot_base[i] + G.edt[i].depc;
+    G.slot_src = calloc(G.slot_base[G.hdr.n_edt] + 1, 8);
+    G.feed_ptr = calloc(G.n_evt_total + 2, 4);
+    /* static pre-pass over main: pre-slot sources and event->event feeders (CSR by destination) */
+    uint32_t *cursor = NULL;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t k = 0; k < G.hdr.n_main; ++k) {
+            const ocrops_op_t *op = &G.main_ops[k];
+            if (op->op != OCROP_ADD_DEP) continue;
+            uint32_t sc = OCRREF_CLS(op->a), dc = OCRREF_CLS(op->b);
+            int src_evt = (sc == OCRREF_EVT || sc == OCRREF_OUTEVT);
+            if (dc == OCRREF_EDT) {
+                if (!pass) { G.slot_src[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = op->a; G.n_sat_edges++; }
+            } else if (src_evt && (dc == OCRREF_EVT || dc == OCRREF_OUTEVT)) {
+                uint32_t x = evt_index(op->b);
+                if (!pass) G.feed_ptr[x + 1]++; else G.feed_idx[cursor[x]++] = evt_index(op->a);
+            }
+        }
+        if (!pass) {
+            for (uint32_t x = 0; x < G.n_evt_total; ++x) G.feed_ptr[x + 1] += G.feed_ptr[x];
+            G.feed_idx = calloc(G.feed_ptr[G.n_evt_total] + 1, 4);
+            cursor = malloc(4 * (G.n_evt_total + 1));
+            memcpy(cursor, G.feed_ptr, 4 * (G.n_evt_total + 1));
+        }
+    }
+    free(cursor);
+    for (uint32_t k = 0; k < G.hdr.n_script; ++k)
+        if (G.script[k].op == OCROP_SATISFY && evt_kind(evt_index(G.script[k].a)) == OCREVT_LATCH) G.n_sat_edges++;
+}
+
+ocrGuid_t mainEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) {
+    void *args = depv[0].ptr;
+    if (getArgc(args) < 3) { fprintf(stderr, "usage: ocr_replay -ocr:cfg <cfg> <ops> <result|->\n"); ocrAbort(2); return NULL_GUID; }
+    load_stream(getArgv(args, 1));
+    G.res_path = getArgv(args, 2);
+    {   /* COUNTED_MAP guids carry the kind in bits 49..53 (guid-bitmap.h:22-71); PTR guids are heap addresses */
+        ocrGuid_t probe; ocrEventCreate(&probe, OCR_EVENT_STICKY_T, EVT_PROP_NONE);
+        G.guid_is_map = (((uint64_t)probe.guid >> 49) & 0x1F) == 21 /* OCR_GUID_EVENT_STICKY */ && ((uint64_t)probe.guid >> 54) == 0;
+        ocrEventDestroy(probe);
+    }
+    ocrGuid_t tpl;
+    ocrEdtTemplateCreate(&tpl, bodyEdt, 1, EDT_PARAM_UNK);
+    for (uint32_t k = 0; k < G.hdr.n_main; ++k) {
+        const ocrops_op_t *op = &G.main_ops[k];
+        switch (op->op) {
+        case OCROP_EVT_CREATE: {
+            uint32_t x = (uint32_t)op->a; const ocrops_evt_t *ev = &G.evt[x];
+            if ((ev->kind == OCREVT_LATCH && ev->arg != 0) || ev->kind == OCREVT_COUNTED) {
+                ocrEventParams_t p; memset(&p, 0, sizeof p);
+                if (ev->kind == OCREVT_LATCH) p.EVENT_LATCH.counter = ev->arg; else p.EVENT_COUNTED.nbDeps = ev->arg;
+                ocrEventCreateParams(&G.evt_guid[x], (ocrEventTypes_t)ev->kind, EVT_PROP_TAKES_ARG, &p);
+            } else
+                ocrEventCreate(&G.evt_guid[x], (ocrEventTypes_t)ev->kind, EVT_PROP_TAKES_ARG);
+        } break;
+        case OCROP_DB_CREATE: {
+            uint32_t d = (uint32_t)op->a; uint64_t *p;
+            ocrDbCreate(&G.db_guid[d], (void **)&p, 16, 0, NULL_HINT, NO_ALLOC);
+            p[0] = G.db_init[d]; p[1] = d; G.db_ptr[d] = p;
+            ocrDbRelease(G.db_guid[d]);
+        } break;
+        case OCROP_EDT_CREATE: {
+            uint32_t e = (uint32_t)op->a; u64 id = e;
+            int oe = (G.edt[e].body & OCRBODY_F_OUTEVT) != 0;
+            ocrEdtCreate(&G.edt_guid[e], tpl, 1, &id, G.edt[e].depc, NULL, EDT_PROP_NONE, NULL_HINT,
+                         oe ? &G.evt_guid[G.hdr.n_evt + e] : NULL);
+        } break;
+        case OCROP_ADD_DEP:
+            ocrAddDependence(ref_guid(op->a, 0, NULL), ref_guid(op->b, 0, NULL), op->slot, (ocrDbAccessMode_t)op->mode);
+            break;
+        case OCROP_SATISFY:
+            if (!G.t0_set) { gettimeofday(&G.t0, NULL); G.t0_set = 1; }
+            do_satisfy(op, 0, CLK_MAIN, NULL);
+            break;
+        case OCROP_EVT_DESTROY: ocrEventDestroy(ref_guid(op->a, 0, NULL)); break;
+        default: fprintf(stderr, "bad op %u\n", op->op); abort();
+        }
+    }
+    return NULL_GUID;
+}
