@@ -225,8 +225,9 @@ def layered_dag(n_edt: int, width: int, seed: int = SEED_BASE + 2, name=None) ->
     hangs off one ONCE ``start`` event (satisfied by the last main op), because a depc==0
     EDT fires inside ocrEdtCreate (hc-task.c:1129-1134) and its output event would be
     satisfied-and-destroyed before its consumers register (hc-event.c:450-464,1078-1083).
-    EDTs nobody consumes DECR one LATCH (initial count = their number) whose post-slot
-    fires the sink EDT #n_edt, which calls ocrShutdown (SURVEY.md s8a rule 10).
+    The output events nobody consumes feed the DECR slot of one LATCH (event->event
+    dependences; initial count = their number) whose post-slot fires the sink EDT #n_edt,
+    which calls ocrShutdown (SURVEY.md s8a rule 10: the sink must depend on all work).
     """
     assert n_edt % width == 0 and n_edt >= width
     n_layers = n_edt // width
@@ -259,10 +260,7 @@ def layered_dag(n_edt: int, width: int, seed: int = SEED_BASE + 2, name=None) ->
     edt["body"][:N] = BODY_HASH | BODY_F_OUTEVT
     edt["depc"][N] = 1
     edt["body"][N] = BODY_NOP | BODY_F_SINK
-    # scripts: leaves DECR the latch
-    script = make_ops(OP_SATISFY, np.full(n_leaves, ref(REF_EVT, EV_LATCH), dtype=np.uint64), b=0, slot=LATCH_DECR)
-    edt["script_begin"][leaves] = np.arange(n_leaves, dtype=np.uint32)
-    edt["script_len"][leaves] = 1
+    script = np.zeros(0, dtype=OP_DT)
     evt = np.zeros(2, dtype=EVT_DT)
     evt["kind"] = [EVT_ONCE, EVT_LATCH]
     evt["arg"] = [0, n_leaves]
@@ -273,6 +271,7 @@ def layered_dag(n_edt: int, width: int, seed: int = SEED_BASE + 2, name=None) ->
         make_ops(OP_ADD_DEP, ref(REF_OUTEVT, src), b=ref(REF_EDT, dst), slot=slot, mode=MODE_RO),
         make_ops(OP_ADD_DEP, np.full(width, ref(REF_EVT, EV_START), dtype=np.uint64),
                  b=ref(REF_EDT, np.arange(width)), slot=0, mode=MODE_NULL),
+        make_ops(OP_ADD_DEP, ref(REF_OUTEVT, leaves), b=ref(REF_EVT, EV_LATCH), slot=LATCH_DECR, mode=MODE_NULL),
         make_ops(OP_ADD_DEP, [ref(REF_EVT, EV_LATCH)], b=ref(REF_EDT, sink), slot=0, mode=MODE_NULL),
         make_ops(OP_SATISFY, [ref(REF_EVT, EV_START)], b=0, slot=0),
     ])
@@ -284,3 +283,95 @@ def layered_dag(n_edt: int, width: int, seed: int = SEED_BASE + 2, name=None) ->
                 n_leaves=n_leaves, n_satisfactions=n_sat, seed=seed)
     return OpStream(edt, evt, np.zeros(0, dtype=np.uint64), main, script, sink,
                     name=name or f"layered_N{N}_W{width}", meta=meta)
+
+
+class Builder:
+    """Write small op streams by hand (tests, examples): objects are plain ints, refs are made for you."""
+
+    def __init__(self, name=""):
+        self.name = name
+        self.edts, self.evts, self.dbs, self.main, self.scripts = [], [], [], [], {}
+        self._sunk = False
+
+    # -- creation (each also emits the main op) --
+    def evt(self, kind, arg=0):
+        self.evts.append((kind, arg))
+        x = len(self.evts) - 1
+        self.main.append((OP_EVT_CREATE, 0, 0, x, 0))
+        return ref(REF_EVT, x)
+
+    def db(self, value):
+        self.dbs.append(value)
+        d = len(self.dbs) - 1
+        self.main.append((OP_DB_CREATE, 0, 0, d, 0))
+        return ref(REF_DB, d)
+
+    def edt(self, depc, body=BODY_HASH, outevt=True, sink=False):
+        b = body | (BODY_F_OUTEVT if outevt else 0) | (BODY_F_SINK if sink else 0)
+        self.edts.append([depc, b])
+        e = len(self.edts) - 1
+        self.main.append((OP_EDT_CREATE, 0, 0, e, 0))
+        return ref(REF_EDT, e)
+
+    @staticmethod
+    def out(edt_ref):
+        return ref(REF_OUTEVT, ref_idx(edt_ref))
+
+    @staticmethod
+    def outdb(edt_ref):
+        return ref(REF_OUTDB, ref_idx(edt_ref))
+
+    @staticmethod
+    def depv(k):
+        return ref(REF_DEPV, k)
+
+    # -- main-program calls --
+    def add_dep(self, src, dst, slot=0, mode=MODE_RO):
+        self.main.append((OP_ADD_DEP, mode, slot, src, dst))
+
+    def satisfy(self, evt, payload=0, slot=0):
+        self.main.append((OP_SATISFY, 0, slot, evt, payload))
+
+    def destroy(self, evt):
+        self.main.append((OP_EVT_DESTROY, 0, 0, evt, 0))
+
+    # -- calls made by an EDT body before it returns --
+    def script_satisfy(self, edt_ref, evt, payload=0, slot=0):
+        self.scripts.setdefault(ref_idx(edt_ref), []).append((OP_SATISFY, 0, slot, evt, payload))
+
+    def script_destroy(self, edt_ref, evt):
+        self.scripts.setdefault(ref_idx(edt_ref), []).append((OP_EVT_DESTROY, 0, 0, evt, 0))
+
+    def finish(self, expected, start=None):
+        """Add the sink: a LATCH counting the EDTs in ``expected`` (through their output event
+        when they have one, else through a script DECR) fires the sink EDT.  ``start`` (an
+        event ref) is satisfied as the very last main op."""
+        latch = self.evt(EVT_LATCH, len(expected))
+        sink = self.edt(1, BODY_NOP, outevt=False, sink=True)
+        for e in expected:
+            if self.edts[ref_idx(e)][1] & BODY_F_OUTEVT:
+                self.add_dep(self.out(e), latch, LATCH_DECR, MODE_NULL)
+            else:
+                self.script_satisfy(e, latch, 0, LATCH_DECR)
+        self.add_dep(latch, sink, 0, MODE_NULL)
+        if start is not None:
+            self.satisfy(start)
+        self._sunk = True
+        return self.build(ref_idx(sink))
+
+    def build(self, sink_edt=0):
+        edt = np.zeros(len(self.edts), dtype=EDT_DT)
+        script = []
+        for i, (depc, body) in enumerate(self.edts):
+            ops = self.scripts.get(i, [])
+            edt[i] = (depc, body, len(script), len(ops))
+            script += ops
+        evt = np.array(self.evts, dtype=EVT_DT) if self.evts else np.zeros(0, dtype=EVT_DT)
+
+        def pack(ops):
+            out = np.zeros(len(ops), dtype=OP_DT)
+            for i, (op, mode, slot, a, b) in enumerate(ops):
+                out[i] = (op, mode, 0, slot, a, b)
+            return out
+        return OpStream(edt, evt, np.array(self.dbs, dtype=np.uint64), pack(self.main), pack(script), sink_edt,
+                        name=self.name)

@@ -1,0 +1,248 @@
+/*
+ * engine_ref.c -- TEST INFRASTRUCTURE: the CPU restatement ("oracle port") of the reference's
+ * dependence-resolution path.  Single-threaded plain C.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product path (ocr_amd/csrc) never does.
+ *
+ * PARITY PINNED: tests/test_oracle_golden.py checks this file against result records produced
+ * by the reference runtime itself (oracle/ocr_replay.c linked to oracle/_ref/libocr_x86_*.a),
+ * committed under tests/golden/, and -- when /root/reference is present -- re-runs the
+ * reference live on the same streams.
+ *
+ * It interprets an op stream (include/ocr_opstream.h) level-synchronously:
+ *   main ops run in order at level -1; every EDT that becomes ready while level k runs
+ *   fires at level k+1 (level = 1 + max level of whatever satisfied its pre-slots).
+ * Semantics restated, with the reference line each follows:
+ *   ONCE   satisfy: fan out to all waiters, then self-destruct, also with zero waiters
+ *          (satisfyEventHcOnce, ocr/src/event/hc/hc-event.c:437-465); registering a waiter
+ *          after that is a user error (registerWaiterEventHc :1078-1083).
+ *   LATCH  counter += (slot==DECR ? -1 : +1); fires iff the new value == 0, INCR included,
+ *          forwarding the triggering payload, then self-destructs
+ *          (satisfyEventHcLatch :812-868,885); initial counter from params (:1579-1589).
+ *   STICKY/IDEM store the payload, fan out, stay alive; a waiter registered later is
+ *          satisfied at once with the stored payload (registerWaiterEventHcPersist
+ *          :1143-1155); 2nd satisfy: IDEM ignores (:601), STICKY is a user error (:577,624).
+ *   EDT    slotSatisfiedCount++; depv[slot].guid = payload, forced NULL when the dependence
+ *          mode is DB_MODE_NULL; fires when count == depc (satisfyTaskHc,
+ *          ocr/src/task/hc/hc-task.c:1253-1266); depc==0 fires at creation (:1129-1134);
+ *          a slot satisfied twice is an error (:1243).
+ *   ocrAddDependence classification (ocr/src/policy-domain/hc/hc-policy.c:2857-3074):
+ *          NULL src -> satisfy(dst,slot,NULL); DB src -> satisfy(dst,slot,db) (mode recorded
+ *          first for an EDT dst, registerSignalerTaskHc hc-task.c:1373,1411-1437);
+ *          event src -> waiter registration on the source event.
+ *   Epilogue: script satisfies (the body's own ocrEventSatisfySlot calls) happen before the
+ *          output event is satisfied with the returned guid (taskEpilogue hc-task.c:1822-1831).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "ocr_opstream.h"
+
+enum { ST_LIVE = 0, ST_SAT = 1, ST_DESTROYED = 2, ST_ABSENT = 3 };
+enum { ERR_DOUBLE_SLOT = 0, ERR_ONCE_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_EVENT = 3, ERR_BAD_OP = 4, N_ERR = 8 };
+
+typedef struct { uint32_t dst, slot; uint8_t dst_is_evt, mode_null; } waiter_t;
+typedef struct { uint32_t kind, state; int32_t counter; uint32_t data; uint32_t n_w, cap_w; waiter_t *w; } event_t;
+typedef struct { uint32_t depc, cnt; uint64_t slot_base; uint8_t created; } edtst_t;
+typedef struct { uint32_t payload; uint8_t sat, mode_null; } slot_t;
+typedef struct { uint32_t idx, slot, payload; uint8_t is_evt, mode_null; } work_t;
+
+typedef struct {
+    const ocrops_hdr_t *h; const ocrops_edt_t *edt; const ocrops_evt_t *evt; const ocrops_op_t *script;
+    event_t *ev; edtst_t *ed; slot_t *slots;
+    work_t *stack; size_t sp, stack_cap;
+    uint32_t *ready_next; size_t n_next, cap_next;
+    uint64_t *db_val; uint8_t *db_live;
+    uint64_t err[N_ERR], n_edge_sat, n_evt_sat;
+} eng_t;
+
+static void push_work(eng_t *E, work_t w) {
+    if (E->sp == E->stack_cap) { E->stack_cap = E->stack_cap ? 2 * E->stack_cap : 1024; E->stack = realloc(E->stack, E->stack_cap * sizeof(work_t)); }
+    E->stack[E->sp++] = w;
+}
+static void push_ready(eng_t *E, uint32_t e) {
+    if (E->n_next == E->cap_next) { E->cap_next = E->cap_next ? 2 * E->cap_next : 1024; E->ready_next = realloc(E->ready_next, E->cap_next * 4); }
+    E->ready_next[E->n_next++] = e;
+}
+static uint32_t ev_index(const eng_t *E, uint64_t r) {
+    return OCRREF_CLS(r) == OCRREF_EVT ? (uint32_t)OCRREF_IDX(r) : E->h->n_evt + (uint32_t)OCRREF_IDX(r);
+}
+/* payload encoding: dbid+1, 0 = NULL_GUID */
+static uint32_t payload_of(const eng_t *E, uint64_t r, uint32_t self, const slot_t *depv) {
+    switch (OCRREF_CLS(r)) {
+    case OCRREF_DB: return (uint32_t)OCRREF_IDX(r) + 1;
+    case OCRREF_OUTDB: return E->h->n_db + (uint32_t)OCRREF_IDX(r) + 1;
+    case OCRREF_DEPV: return depv ? depv[OCRREF_IDX(r)].payload : 0;
+    default: (void)self; return 0;
+    }
+}
+
+static void fan_out(eng_t *E, event_t *v, uint32_t payload) {
+    for (uint32_t i = 0; i < v->n_w; ++i) {
+        work_t w = { v->w[i].dst, v->w[i].slot, payload, v->w[i].dst_is_evt, v->w[i].mode_null };
+        push_work(E, w);
+    }
+}
+
+/* drain the satisfy work stack (depth-first, like the nested processMessage calls of
+ * commonSatisfyRegNode hc-event.c:335-367; the order is not observable in the record) */
+static void drain(eng_t *E) {
+    while (E->sp) {
+        work_t w = E->stack[--E->sp];
+        if (!w.is_evt) { /* satisfyTaskHc */
+            edtst_t *t = &E->ed[w.idx];
+            slot_t *s = &E->slots[t->slot_base + w.slot];
+            E->n_edge_sat++;
+            if (s->sat) { E->err[ERR_DOUBLE_SLOT]++; continue; }
+            s->sat = 1;
+            s->payload = (w.mode_null || s->mode_null) ? 0 : w.payload;
+            if (++t->cnt == t->depc) push_ready(E, w.idx);
+            continue;
+        }
+        event_t *v = &E->ev[w.idx];
+        E->n_evt_sat++;
+        if (v->state == ST_DESTROYED || v->state == ST_ABSENT) { E->err[ERR_DEAD_EVENT]++; continue; }
+        switch (v->kind) {
+        case OCREVT_ONCE:
+            fan_out(E, v, w.payload); v->state = ST_DESTROYED; break;
+        case OCREVT_LATCH:
+            v->counter += (w.slot == OCRLATCH_DECR) ? -1 : 1;
+            if (v->counter == 0) { fan_out(E, v, w.payload); v->state = ST_DESTROYED; }
+            break;
+        case OCREVT_IDEM: case OCREVT_STICKY:
+            if (v->state == ST_SAT) { if (v->kind == OCREVT_STICKY) E->err[ERR_STICKY_RESAT]++; break; }
+            v->data = w.payload; v->state = ST_SAT; fan_out(E, v, w.payload); break;
+        default: E->err[ERR_BAD_OP]++; break;
+        }
+    }
+}
+
+static void add_waiter(eng_t *E, event_t *v, waiter_t w) {
+    if (v->n_w == v->cap_w) { v->cap_w = v->cap_w ? 2 * v->cap_w : 4; v->w = realloc(v->w, v->cap_w * sizeof(waiter_t)); }
+    v->w[v->n_w++] = w;
+}
+
+static void op_add_dep(eng_t *E, const ocrops_op_t *op) {
+    uint32_t sc = OCRREF_CLS(op->a), dc = OCRREF_CLS(op->b);
+    int dst_is_evt = (dc == OCRREF_EVT || dc == OCRREF_OUTEVT);
+    uint32_t dst = dst_is_evt ? ev_index(E, op->b) : (uint32_t)OCRREF_IDX(op->b);
+    uint8_t mode_null = (!dst_is_evt && op->mode == OCRMODE_NULL);
+    if (sc == OCRREF_NULL || sc == OCRREF_DB || sc == OCRREF_OUTDB) {
+        /* convertDepAddToSatisfy hc-policy.c:2857-2902; DB->EDT records the mode first */
+        uint8_t mn = (sc == OCRREF_NULL) ? 0 : mode_null; /* NULL src: mode not recorded (signalers[].mode stays -1) */
+        work_t w = { dst, op->slot, payload_of(E, op->a, 0, NULL), (uint8_t)dst_is_evt, mn };
+        push_work(E, w); drain(E);
+        return;
+    }
+    if (sc != OCRREF_EVT && sc != OCRREF_OUTEVT) { E->err[ERR_BAD_OP]++; return; }
+    event_t *v = &E->ev[ev_index(E, op->a)];
+    if (!dst_is_evt) E->slots[E->ed[dst].slot_base + op->slot].mode_null = mode_null; /* registerSignalerTaskHc :1373 */
+    if (v->state == ST_DESTROYED || v->state == ST_ABSENT) { E->err[ERR_ONCE_LATE_WAITER]++; return; }
+    if (v->state == ST_SAT) { /* persistent, already satisfied: immediate satisfy with stored data */
+        work_t w = { dst, op->slot, v->data, (uint8_t)dst_is_evt, mode_null };
+        push_work(E, w); drain(E);
+        return;
+    }
+    waiter_t w = { dst, op->slot, (uint8_t)dst_is_evt, mode_null };
+    add_waiter(E, v, w);
+}
+
+static void op_satisfy(eng_t *E, const ocrops_op_t *op, uint32_t self, const slot_t *depv) {
+    uint32_t c = OCRREF_CLS(op->a);
+    uint32_t payload = payload_of(E, op->b, self, depv);
+    if (c == OCRREF_EVT || c == OCRREF_OUTEVT) { work_t w = { ev_index(E, op->a), op->slot, payload, 1, 0 }; push_work(E, w); }
+    else if (c == OCRREF_EDT) { work_t w = { (uint32_t)OCRREF_IDX(op->a), op->slot, payload, 0, 0 }; push_work(E, w); }
+    else if (c == OCRREF_NULL) return; /* ocrEventSatisfy(NULL_GUID, ..) no-op, ocr-edt.c:171 */
+    else { E->err[ERR_BAD_OP]++; return; }
+    drain(E);
+}
+
+static void op_evt_destroy(eng_t *E, uint64_t r) {
+    event_t *v = &E->ev[ev_index(E, r)];
+    if (v->state == ST_DESTROYED || v->state == ST_ABSENT) { E->err[ERR_DEAD_EVENT]++; return; }
+    v->state = ST_DESTROYED;
+}
+
+/* taskExecute + taskEpilogue for one ready EDT (hc-task.c:1864-2181, 1707-1862) */
+static void fire(eng_t *E, uint32_t e, int32_t lvl, int32_t *level, uint64_t *val) {
+    const ocrops_edt_t *d = &E->edt[e];
+    const slot_t *depv = &E->slots[E->ed[e].slot_base];
+    uint64_t v = ocrops_hash_init(e);
+    for (uint32_t i = 0; i < d->depc; ++i) {
+        uint32_t p = depv[i].payload;
+        uint64_t pv = (p && E->db_live[p - 1]) ? E->db_val[p - 1] : 0;
+        v = ocrops_hash_step(v, i, pv, p);
+    }
+    level[e] = lvl; val[e] = v;
+    uint32_t ret = 0;
+    switch (OCRBODY_KIND(d->body)) {
+    case OCRBODY_HASH: ret = E->h->n_db + e + 1; E->db_val[ret - 1] = v; E->db_live[ret - 1] = 1; break;
+    case OCRBODY_FWD0: ret = d->depc ? depv[0].payload : 0; break;
+    default: break;
+    }
+    for (uint32_t k = 0; k < d->script_len; ++k) {
+        const ocrops_op_t *op = &E->script[d->script_begin + k];
+        if (op->op == OCROP_SATISFY) op_satisfy(E, op, e, depv);
+        else if (op->op == OCROP_EVT_DESTROY) op_evt_destroy(E, op->a);
+        else E->err[ERR_BAD_OP]++;
+    }
+    if (d->body & OCRBODY_F_OUTEVT) { work_t w = { E->h->n_evt + e, 0, ret, 1, 0 }; push_work(E, w); drain(E); }
+}
+
+/* Run a whole stream.  Outputs sized as in include/ocr_opstream.h; stats[16]:
+ * [0] levels run, [1] EDTs fired, [2] EDT pre-slot satisfies, [3] event pre-slot satisfies, [8+i] error counters */
+int ocrref_run(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_t *evt, const uint64_t *db_init,
+               const ocrops_op_t *main_ops, const ocrops_op_t *script,
+               int32_t *level, uint64_t *val, uint64_t *evt_state, uint64_t *db_val, uint64_t *stats) {
+    eng_t E; memset(&E, 0, sizeof E);
+    E.h = h; E.edt = edt; E.evt = evt; E.script = script;
+    uint32_t n_evt_total = h->n_evt + h->n_edt, n_db_total = h->n_db + h->n_edt;
+    E.ev = calloc(n_evt_total + 1, sizeof(event_t));
+    E.ed = calloc(h->n_edt + 1, sizeof(edtst_t));
+    uint64_t ns = 0;
+    for (uint32_t i = 0; i < h->n_edt; ++i) { E.ed[i].depc = edt[i].depc; E.ed[i].slot_base = ns; ns += edt[i].depc; }
+    E.slots = calloc(ns + 1, sizeof(slot_t));
+    E.db_val = db_val; memset(db_val, 0, 8 * (size_t)n_db_total);
+    E.db_live = calloc(n_db_total + 1, 1);
+    for (uint32_t x = 0; x < n_evt_total; ++x) E.ev[x].state = ST_ABSENT;
+    memset(level, 0xFF, 4 * (size_t)h->n_edt); memset(val, 0, 8 * (size_t)h->n_edt);
+
+    for (uint32_t k = 0; k < h->n_main; ++k) {
+        const ocrops_op_t *op = &main_ops[k];
+        switch (op->op) {
+        case OCROP_EVT_CREATE: { event_t *v = &E.ev[op->a]; v->kind = evt[op->a].kind; v->state = ST_LIVE;
+                                  v->counter = (v->kind == OCREVT_LATCH) ? evt[op->a].arg : 0; } break;
+        case OCROP_DB_CREATE: E.db_val[op->a] = db_init[op->a]; E.db_live[op->a] = 1; break;
+        case OCROP_EDT_CREATE: { uint32_t e = (uint32_t)op->a; E.ed[e].created = 1;
+                                  if (edt[e].body & OCRBODY_F_OUTEVT) { event_t *v = &E.ev[h->n_evt + e]; v->kind = OCREVT_ONCE; v->state = ST_LIVE; }
+                                  if (edt[e].depc == 0) push_ready(&E, e); } break;
+        case OCROP_ADD_DEP: op_add_dep(&E, op); break;
+        case OCROP_SATISFY: op_satisfy(&E, op, 0, NULL); break;
+        case OCROP_EVT_DESTROY: op_evt_destroy(&E, op->a); break;
+        default: E.err[ERR_BAD_OP]++; break;
+        }
+    }
+    int32_t lvl = 0; uint64_t fired = 0;
+    uint32_t *cur = NULL; size_t n_cur = 0;
+    while (E.n_next) {
+        free(cur); cur = E.ready_next; n_cur = E.n_next;
+        E.ready_next = NULL; E.n_next = E.cap_next = 0;
+        for (size_t i = 0; i < n_cur; ++i) fire(&E, cur[i], lvl, level, val);
+        fired += n_cur; ++lvl;
+    }
+    free(cur);
+    for (uint32_t x = 0; x < n_evt_total; ++x) {
+        event_t *v = &E.ev[x];
+        switch (v->state) {
+        case ST_ABSENT: evt_state[x] = OCREVS(OCREVS_ABSENT, 0); break;
+        case ST_DESTROYED: evt_state[x] = OCREVS(OCREVS_DESTROYED, 0); break;
+        case ST_SAT: evt_state[x] = OCREVS(OCREVS_LIVE_SAT, v->data); break;
+        default: evt_state[x] = OCREVS(OCREVS_LIVE_UNSAT, v->kind == OCREVT_LATCH ? (uint32_t)v->counter : 0); break;
+        }
+        free(v->w);
+    }
+    if (stats) { memset(stats, 0, 16 * 8); stats[0] = (uint64_t)lvl; stats[1] = fired; stats[2] = E.n_edge_sat; stats[3] = E.n_evt_sat;
+                 for (int i = 0; i < N_ERR; ++i) stats[8 + i] = E.err[i]; }
+    free(E.ev); free(E.ed); free(E.slots); free(E.db_live); free(E.stack); free(E.ready_next);
+    return 0;
+}

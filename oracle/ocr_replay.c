@@ -226,6 +226,7 @@ static void load_stream(const char *path) {
                 if (!pass) { G.slot_src[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = op->a; G.n_sat_edges++; }
             } else if (src_evt && (dc == OCRREF_EVT || dc == OCRREF_OUTEVT)) {
                 uint32_t x = evt_index(op->b);
+                if (!pass && evt_kind(x) == OCREVT_LATCH) G.n_sat_edges++;
                 if (!pass) G.feed_ptr[x + 1]++; else G.feed_idx[cursor[x]++] = evt_index(op->a);
             }
         }
@@ -278,6 +279,11 @@ ocrGuid_t mainEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) {
                          oe ? &G.evt_guid[G.hdr.n_evt + e] : NULL);
         } break;
         case OCROP_ADD_DEP:
+            {   /* (db|NULL, event) is an immediate satisfy (hc-policy.c:2857-2902): note its clock */
+                uint32_t sc = OCRREF_CLS(op->a), dc = OCRREF_CLS(op->b);
+                if ((sc == OCRREF_NULL || sc == OCRREF_DB || sc == OCRREF_OUTDB) && (dc == OCRREF_EVT || dc == OCRREF_OUTEVT))
+                    clk_note(evt_index(op->b), CLK_MAIN);
+            }
             ocrAddDependence(ref_guid(op->a, 0, NULL), ref_guid(op->b, 0, NULL), op->slot, (ocrDbAccessMode_t)op->mode);
             break;
         case OCROP_SATISFY:

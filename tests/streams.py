@@ -1,0 +1,239 @@
+"""Hand-written op streams that pin the semantic rules of SURVEY.md s8(a) (rules 1-7, 11).
+
+Each mirrors what the reference's own non-regression tests exercise (ocr/tests/non-regression-tests/
+events/testOcrEventLatch*.c, testOcrEventOnce*.c, testOcrEventIdem*.c, testOcrEventMixed*.c,
+testOcrEventToEventDeps0.c, testOcrAddDeps*.c, testOcrDepv*.c, testOcrOutputEvent*.c,
+testOcrEventParam*.c, dist/testDuplicateDeps*.c) as data, so all three executors can run them.
+Every stream is well formed: its outcome does not depend on the schedule.
+"""
+from ocr_amd.opstream import (BODY_FWD0, BODY_HASH, BODY_NOP, EVT_IDEM, EVT_LATCH, EVT_ONCE, EVT_STICKY,
+                              LATCH_DECR, LATCH_INCR, MODE_NULL, MODE_RO, MODE_RW, Builder, layered_dag)
+
+
+def chain(b, n, start):
+    """n HASH EDTs in a chain hanging off event `start`; returns the list (levels 0..n-1)."""
+    out, prev = [], start
+    for _ in range(n):
+        e = b.edt(1)
+        b.add_dep(prev, e, 0, MODE_RO)
+        out.append(e)
+        prev = b.out(e)
+    return out
+
+
+def latch_decr_then_incr():
+    """Rule 1: fires when the signed counter becomes 0 after ANY op; DECR,INCR on a fresh latch fires."""
+    b = Builder("latch_decr_then_incr")
+    start = b.evt(EVT_ONCE)
+    l = b.evt(EVT_LATCH)
+    a = b.edt(1)
+    b.add_dep(l, a, 0, MODE_NULL)
+    c = chain(b, 2, start)
+    b.script_satisfy(c[0], l, 0, LATCH_DECR)   # level 0: counter -1
+    b.script_satisfy(c[1], l, 0, LATCH_INCR)   # level 1: counter 0 -> fires
+    return b.finish([a] + c, start)
+
+
+def latch_incr2_decr2():
+    """INCR,INCR,DECR,DECR: fires on the last DECR only."""
+    b = Builder("latch_incr2_decr2")
+    start = b.evt(EVT_ONCE)
+    l = b.evt(EVT_LATCH)
+    a = b.edt(1)
+    b.add_dep(l, a, 0, MODE_RO)
+    c = chain(b, 4, start)
+    for e, s in zip(c, (LATCH_INCR, LATCH_INCR, LATCH_DECR, LATCH_DECR)):
+        b.script_satisfy(e, l, b.outdb(e), s)   # the waiter sees the payload of the triggering DECR
+    return b.finish([a] + c, start)
+
+
+def latch_init_counter():
+    """testOcrEventParam: initial counter 3, DECRs at three different levels, payload forwarded."""
+    b = Builder("latch_init_counter")
+    start = b.evt(EVT_ONCE)
+    l = b.evt(EVT_LATCH, 3)
+    a = b.edt(2)
+    b.add_dep(l, a, 0, MODE_RO)
+    b.add_dep(l, a, 1, MODE_NULL)   # same latch, second slot, control only
+    c = chain(b, 3, start)
+    for e in c:
+        b.script_satisfy(e, l, b.outdb(e), LATCH_DECR)
+    never = b.evt(EVT_LATCH, 2)      # stays alive with counter 1
+    b.script_satisfy(c[0], never, 0, LATCH_DECR)
+    return b.finish([a] + c, start)
+
+
+def once_no_waiters():
+    """Rule 2: a ONCE satisfied with zero waiters is dropped and destroyed."""
+    b = Builder("once_no_waiters")
+    start = b.evt(EVT_ONCE)
+    lonely = b.evt(EVT_ONCE)
+    untouched = b.evt(EVT_ONCE)  # never satisfied: stays alive
+    c = chain(b, 2, start)
+    b.script_satisfy(c[0], lonely, b.outdb(c[0]))
+    tail = b.edt(1, outevt=True)   # its output event has no waiter except the sink latch
+    b.add_dep(b.out(c[1]), tail, 0)
+    return b.finish(c + [tail], start)
+
+
+def sticky_early_and_late():
+    """Rule 3: waiters registered before AND after a STICKY's satisfaction all get its payload."""
+    b = Builder("sticky_early_and_late")
+    start = b.evt(EVT_ONCE)
+    d = b.db(0x1111)
+    st_main = b.evt(EVT_STICKY)
+    b.satisfy(st_main, d)                 # satisfied by main before anyone registers
+    late = b.edt(2)
+    b.add_dep(st_main, late, 0, MODE_RO)  # immediate satisfy with the stored guid
+    b.add_dep(start, late, 1, MODE_NULL)
+    st = b.evt(EVT_STICKY)
+    early = b.edt(1)
+    b.add_dep(st, early, 0, MODE_RO)
+    c = chain(b, 2, start)
+    b.script_satisfy(c[1], st, b.outdb(c[1]))
+    st_null = b.evt(EVT_STICKY)           # satisfied with NULL_GUID
+    b.script_satisfy(c[0], st_null, 0)
+    en = b.edt(1)
+    b.add_dep(st_null, en, 0, MODE_RO)
+    st_never = b.evt(EVT_STICKY)          # never satisfied
+    blocked = b.edt(1)                    # never fires
+    b.add_dep(st_never, blocked, 0)
+    return b.finish([late, early, en] + c, start)
+
+
+def idem_double_satisfy():
+    """Rule 3: the 2nd satisfy of an IDEM is ignored; everybody sees the first payload."""
+    b = Builder("idem_double_satisfy")
+    start = b.evt(EVT_ONCE)
+    idem = b.evt(EVT_IDEM)
+    w0 = b.edt(1)
+    b.add_dep(idem, w0, 0, MODE_RO)
+    c = chain(b, 3, start)
+    b.script_satisfy(c[0], idem, b.outdb(c[0]))
+    b.script_satisfy(c[2], idem, b.outdb(c[2]))   # ignored
+    idem2 = b.evt(EVT_IDEM)
+    d = b.db(77)
+    b.satisfy(idem2, d)
+    b.satisfy(idem2, 0)                            # ignored, from main
+    w1 = b.edt(2)
+    b.add_dep(idem2, w1, 0, MODE_RO)
+    b.add_dep(start, w1, 1, MODE_NULL)
+    return b.finish([w0, w1] + c, start)
+
+
+def mode_null_forces_null():
+    """Rule 5: depv[slot].guid is forced to NULL_GUID when the dependence mode is DB_MODE_NULL."""
+    b = Builder("mode_null_forces_null")
+    start = b.evt(EVT_ONCE)
+    c = chain(b, 1, start)
+    a = b.edt(3)
+    b.add_dep(b.out(c[0]), a, 0, MODE_NULL)
+    b.add_dep(b.out(c[0]), a, 1, MODE_RO)
+    b.add_dep(b.out(c[0]), a, 2, MODE_RW)
+    d = b.db(5)
+    x = b.edt(3)
+    b.add_dep(d, x, 0, MODE_NULL)    # DB -> EDT with NULL mode: recorded, payload dropped
+    b.add_dep(d, x, 1, MODE_RO)      # rule 6: same DB on two slots
+    b.add_dep(start, x, 2, MODE_NULL)
+    return b.finish(c + [a, x], start)
+
+
+def db_and_null_sources():
+    """Rule 7: ocrAddDependence(NULL_GUID, edt, slot) == satisfy(NULL); (db, evt) == satisfy(evt, db)."""
+    b = Builder("db_and_null_sources")
+    start = b.evt(EVT_ONCE)
+    d0, d1 = b.db(10), b.db(20)
+    e = b.edt(4)
+    b.add_dep(d0, e, 0, MODE_RO)
+    b.add_dep(0, e, 1, MODE_RO)       # NULL source
+    b.add_dep(d1, e, 2, MODE_RW)
+    b.add_dep(start, e, 3, MODE_NULL)
+    once = b.evt(EVT_ONCE)
+    f = b.edt(2)
+    b.add_dep(once, f, 0, MODE_RO)
+    b.add_dep(start, f, 1, MODE_NULL)
+    b.add_dep(d1, once, 0)            # DB -> event == satisfy
+    return b.finish([e, f], start)
+
+
+def event_chain():
+    """testOcrEventToEventDeps0: once -> once -> sticky -> latch(1) -> EDT; payload forwarded unchanged."""
+    b = Builder("event_chain")
+    start = b.evt(EVT_ONCE)
+    c = chain(b, 2, start)
+    o1, o2, st, l = b.evt(EVT_ONCE), b.evt(EVT_ONCE), b.evt(EVT_STICKY), b.evt(EVT_LATCH, 1)
+    b.add_dep(o1, o2, 0)
+    b.add_dep(o2, st, 0)
+    b.add_dep(st, l, LATCH_DECR)
+    a = b.edt(2)
+    b.add_dep(l, a, 0, MODE_RO)
+    b.add_dep(st, a, 1, MODE_RO)
+    b.add_dep(b.out(c[1]), o1, 0)     # output event -> event
+    fan = [b.edt(1) for _ in range(9)]  # > HCEVT_WAITER_STATIC_COUNT waiters on one event
+    for f in fan:
+        b.add_dep(o2, f, 0, MODE_RO)
+    return b.finish(c + [a] + fan, start)
+
+
+def forward_and_nop():
+    """testOcrOutputEvent: the output event carries whatever guid the body returns (FWD0 / NULL)."""
+    b = Builder("forward_and_nop")
+    start = b.evt(EVT_ONCE)
+    d = b.db(0xABCD)
+    fw = b.edt(2, BODY_FWD0)
+    b.add_dep(d, fw, 0, MODE_RO)
+    b.add_dep(start, fw, 1, MODE_NULL)
+    nop = b.edt(1, BODY_NOP)
+    b.add_dep(start, nop, 0, MODE_NULL)
+    a = b.edt(2)
+    b.add_dep(b.out(fw), a, 0, MODE_RO)
+    b.add_dep(b.out(nop), a, 1, MODE_RO)
+    quiet = b.edt(1, BODY_NOP, outevt=False)   # no output event at all
+    b.add_dep(b.out(a), quiet, 0, MODE_RO)
+    return b.finish([fw, nop, a, quiet], start)
+
+
+def destroy_and_unfired():
+    """ocrEventDestroy on persistent events; EDTs whose slots never fill stay unfired."""
+    b = Builder("destroy_and_unfired")
+    start = b.evt(EVT_ONCE)
+    st = b.evt(EVT_STICKY)
+    c = chain(b, 3, start)
+    w = b.edt(1)
+    b.add_dep(st, w, 0, MODE_RO)
+    b.script_satisfy(c[0], st, b.outdb(c[0]))
+    b.script_destroy(c[2], st)                 # destroyed two levels after its satisfaction
+    st2 = b.evt(EVT_IDEM)
+    b.destroy(st2)                             # created and destroyed by main, never used
+    half = b.edt(2)                            # only one of two slots is ever satisfied
+    b.add_dep(b.out(c[0]), half, 0, MODE_RO)
+    return b.finish(c + [w], start)
+
+
+def wide_fanin():
+    """One EDT with 40 pre-slots fed from 40 producers on two levels + a 200-waiter ONCE."""
+    b = Builder("wide_fanin")
+    start = b.evt(EVT_ONCE)
+    prods = []
+    for i in range(20):
+        c = chain(b, 2, start)
+        prods += c
+    big = b.edt(40)
+    for i, p in enumerate(prods):
+        b.add_dep(b.out(p), big, i, MODE_RO if i % 3 else MODE_NULL)
+    fan = [b.edt(1) for _ in range(200)]
+    for f in fan:
+        b.add_dep(b.out(big), f, 0, MODE_RO)
+    return b.finish(prods + [big] + fan, start)
+
+
+SEMANTIC = [latch_decr_then_incr, latch_incr2_decr2, latch_init_counter, once_no_waiters, sticky_early_and_late,
+            idem_double_satisfy, mode_null_forces_null, db_and_null_sources, event_chain, forward_and_nop,
+            destroy_and_unfired, wide_fanin]
+
+
+def all_streams():
+    out = [f() for f in SEMANTIC]
+    out.append(layered_dag(1000, 100, name="layered_1k"))
+    out.append(layered_dag(100_000, 1000, name="layered_100k"))
+    return out
