@@ -1,0 +1,165 @@
+/*
+ * ocrgpu.h -- C-ABI of libocrgpu, the MI355X (gfx950) dependence-resolution engine.
+ *
+ * Plain C, opaque handle, plain pointers and sizes.  This is the boundary the OCR component
+ * factories bind to (INTEGRATION.md shows the C stubs): a GUID provider, a scheduler
+ * heuristic / workpile and the event+task bookkeeping behind the policy domain's DEP_* and
+ * WORK_* messages call these entry points instead of walking ocrPolicyMsg_t through
+ * hcPolicyDomainProcessMessage (ocr/src/policy-domain/hc/hc-policy.c:1722).
+ *
+ * Calling convention
+ *  - every call returns 0 or a negative OCRGPU_E* code (ocr/inc/ocr-errors.h convention: 0 = ok);
+ *  - all calls are BATCHED: n objects per call, struct-of-arrays;  `where` says whether the
+ *    arrays live in host memory (OCRGPU_HOST, staged over PCIe by the engine) or are device
+ *    pointers on the engine's GPU (OCRGPU_DEVICE, no copy);
+ *  - batches are applied in call order on the engine's stream; within one batch the order of
+ *    elements is not observable for well-formed programs (the reference gives the same freedom
+ *    to concurrent workers);
+ *  - one engine = one GPU = one policy-domain partition (location); not thread safe: one
+ *    caller at a time per engine (the host shim serialises).
+ */
+#ifndef OCRGPU_H
+#define OCRGPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ocrgpu_engine ocrgpu_engine_t;
+
+enum { OCRGPU_HOST = 0, OCRGPU_DEVICE = 1 };
+
+enum {
+    OCRGPU_OK = 0,
+    OCRGPU_EINVAL = -22,   /* bad argument (OCR_EINVAL)                                  */
+    OCRGPU_ENOMEM = -12,   /* a capacity given at init is exhausted (OCR_ENOMEM)         */
+    OCRGPU_EHIP = -5,      /* a HIP runtime call failed; ocrgpu_last_error() has the text */
+    OCRGPU_ENODEV = -19,   /* no usable gfx950 device                                    */
+    OCRGPU_EFAULT = -14,   /* the device flagged a user-level error (see stats.err[])    */
+    OCRGPU_ENOTSUP = -95
+};
+
+/* GUID bit layout == the reference's COUNTED_MAP provider: LOCHOME(10) | KIND(5) | COUNTER(49),
+ * MSB->LSB (ocr/src/guid/guid-bitmap.h:22-71, GUID_PROVIDER_LOCID_SIZE=10 ocr/build/common.mk:92,
+ * counted-map-guid.c:43).  Kinds == ocrGuidKind (ocr/src/inc/ocr-guid-kind.h:19-44). */
+enum {
+    OCRGPU_KIND_DB = 2, OCRGPU_KIND_EDT = 3, OCRGPU_KIND_EVENT = 16 /* bit 0x10 */,
+    OCRGPU_KIND_EVT_ONCE = 17, OCRGPU_KIND_EVT_COUNTED = 18, OCRGPU_KIND_EVT_IDEM = 19,
+    OCRGPU_KIND_EVT_STICKY = 21, OCRGPU_KIND_EVT_LATCH = 22, OCRGPU_KIND_EVT_CHANNEL = 23
+};
+#define OCRGPU_GUID_KIND(g)     ((uint32_t)(((uint64_t)(g) >> 49) & 0x1F))   /* getKindFromGuid  guid-bitmap-based.c:19 */
+#define OCRGPU_GUID_LOCATION(g) ((uint32_t)((uint64_t)(g) >> 54))            /* extractLocIdFromGuid :31 */
+#define OCRGPU_GUID_COUNTER(g)  ((uint64_t)(g) & ((1ULL << 49) - 1))
+#define OCRGPU_NULL_GUID   0ULL
+#define OCRGPU_ERROR_GUID  (~0ULL)          /* ocr/inc/ocr-types.h:61-68 */
+#define OCRGPU_UNINIT_GUID (~0ULL - 1)
+
+typedef struct {
+    uint32_t max_edt;      /* EDTs this partition can hold                                   */
+    uint32_t max_evt;      /* explicitly created events (output events come with the EDTs)   */
+    uint32_t max_db;       /* explicitly created datablocks (output DBs come with the EDTs)  */
+    uint32_t location;     /* LOCHOME id of this partition (== rank)                          */
+    uint64_t max_slots;    /* sum of depc over all EDTs                                       */
+    uint64_t max_edges;    /* waiter registrations (event -> EDT|event dependences), < 2^32   */
+    uint64_t guid_slots;   /* GUID table slots (power of two); 0 = 2x the object capacity     */
+    uint32_t max_levels;   /* level boundaries recorded (0 = 1<<20)                           */
+    uint32_t flags;        /* OCRGPU_F_*                                                      */
+} ocrgpu_config_t;
+#define OCRGPU_F_NANNY 1u  /* detect double satisfy of an EDT pre-slot (hc-task.c:1243); +1 atomic per edge */
+#define OCRGPU_F_TIMING 2u /* bracket resolve's kernels with HIP events on the engine stream   */
+
+typedef struct {
+    uint64_t levels;        /* topological levels run by the last resolve                      */
+    uint64_t fired;         /* EDTs fired                                                      */
+    uint64_t edt_sat;       /* satisfies applied to EDT pre-slots   (satisfyTaskHc calls)      */
+    uint64_t evt_sat;       /* satisfies applied to event pre-slots (event.satisfy calls)      */
+    uint64_t launches;      /* k_step launches (incl. the no-op ones issued ahead)             */
+    uint64_t step_kernel_ns;/* OCRGPU_F_TIMING: HIP-event time over all k_step launches        */
+    uint64_t err[8];        /* [0] double slot satisfy [1] waiter on dead non-persistent event
+                               [2] STICKY re-satisfied [3] satisfy/destroy of a dead event
+                               [4] malformed op / unknown guid [5] queue overflow [6] level log overflow */
+} ocrgpu_stats_t;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_config_t *cfg);
+int ocrgpu_fini(ocrgpu_engine_t *e);
+int ocrgpu_set_stream(ocrgpu_engine_t *e, void *hip_stream);    /* default: the NULL stream */
+const char *ocrgpu_last_error(void);
+int ocrgpu_abi_version(void);
+
+/* ---- GUID provider (replaces ocrGuidProviderFcts_t, ocr/src/inc/ocr-guid.h:86-314, COUNTED_MAP impl
+ *      ocr/src/guid/counted/counted-map-guid.c:222-572 + ocr/src/utils/hashtable.c:461-554) ------ */
+/* getGuid/createGuid: reserve n consecutive counters of `kind`; guids_out[i] = LOC|KIND|counter+i  (:222-300) */
+int ocrgpu_guid_reserve(ocrgpu_engine_t *e, uint32_t kind, uint64_t n, uint64_t *guids_out, int where);
+/* registerGuid / hashtable put (:302, hashtable.c:498): vals must be non-zero */
+int ocrgpu_guid_put(ocrgpu_engine_t *e, uint64_t n, const uint64_t *guids, const uint64_t *vals, int where);
+/* getVal (:394-406, hashtable.c:461): vals_out[i] = 0 when the guid does not resolve */
+int ocrgpu_guid_get(ocrgpu_engine_t *e, uint64_t n, const uint64_t *guids, uint64_t *vals_out, int where);
+/* releaseGuid / unregisterGuid (:527-572, hashtable.c:527) */
+int ocrgpu_guid_remove(ocrgpu_engine_t *e, uint64_t n, const uint64_t *guids, int where);
+
+/* ---- object creation (replace newEventHc hc-event.c:1558-1765, newTaskHc hc-task.c:871-1136,
+ *      hcAllocateDb hc-policy.c:752-784).  Objects get engine indices in creation order;
+ *      ocrgpu_guid_get() on an engine-made guid returns (index + 1).                       ------ */
+/* ocrEventCreateParams (ocr-edt.c:19): kind = ocrEventTypes_t 1..4; arg = LATCH initial counter */
+int ocrgpu_event_create(ocrgpu_engine_t *e, uint64_t n, const uint32_t *kind, const int32_t *arg,
+                        uint64_t *guids_out, int where);
+/* ocrDbCreate (ocr-db.h:78): a DB here is a 16-byte payload {value, tag}                    */
+int ocrgpu_db_create(ocrgpu_engine_t *e, uint64_t n, const uint64_t *value, const uint64_t *tag,
+                     uint64_t *guids_out, int where);
+/* ocrEdtCreate with depv == NULL (ocr-edt.c:295): body = OCRBODY_* | OCRBODY_F_OUTEVT (ocr_opstream.h),
+ * param0 = paramv[0].  outevt_guids_out[i] = guid of the ONCE output event or NULL_GUID.  depc==0
+ * EDTs become ready at once (hc-task.c:1129-1134).  outevt_guids_out / outdb_guids_out may be NULL. */
+int ocrgpu_edt_create(ocrgpu_engine_t *e, uint64_t n, const uint32_t *depc, const uint32_t *body,
+                      const uint64_t *param0, uint64_t *guids_out, uint64_t *outevt_guids_out,
+                      uint64_t *outdb_guids_out, int where);
+/* the satisfies an EDT body performs before returning (its own ocrEventSatisfySlot calls):
+ * EDT edt[i] runs ops[begin[i] .. begin[i]+len[i]).  target = event guid; payload_kind selects
+ * NULL_GUID / a DB guid in `payload` / the EDT's own output DB / depv[payload].guid            */
+typedef struct { uint64_t target, payload; uint32_t slot; uint8_t op, payload_kind; uint16_t pad; } ocrgpu_script_op_t;
+enum { OCRGPU_PAY_NULL = 0, OCRGPU_PAY_GUID = 1, OCRGPU_PAY_OUTDB = 2, OCRGPU_PAY_DEPV = 3 };
+enum { OCRGPU_SOP_SATISFY = 5, OCRGPU_SOP_EVT_DESTROY = 6 };
+int ocrgpu_edt_set_scripts(ocrgpu_engine_t *e, uint64_t n, const uint64_t *edt, const uint32_t *begin,
+                           const uint32_t *len, uint64_t n_ops, const ocrgpu_script_op_t *ops, int where);
+/* tag written into the DB a HASH body creates = tag_base + param0 (what the replayed OCR program writes) */
+int ocrgpu_set_hash_tag_base(ocrgpu_engine_t *e, uint64_t tag_base);
+
+/* ---- dependence API (replace PD_MSG_DEP_ADD / DEP_REGWAITER / DEP_REGSIGNALER / DEP_SATISFY,
+ *      hc-policy.c:2775-3280; registerWaiterEventHc* hc-event.c:1065-1163; satisfy* :437-886) ---- */
+/* ocrAddDependence(src, dst, slot, mode) (ocr-edt.c:551) */
+int ocrgpu_add_dependence(ocrgpu_engine_t *e, uint64_t n, const uint64_t *src, const uint64_t *dst,
+                          const uint32_t *slot, const uint32_t *mode, int where);
+/* ocrEventSatisfySlot(evt, db, slot) (ocr-edt.c:127).  Takes effect (fan-out through events) at
+ * once; EDTs that become ready wait for ocrgpu_resolve / ocrgpu_step.                          */
+int ocrgpu_event_satisfy_slot(ocrgpu_engine_t *e, uint64_t n, const uint64_t *evt, const uint64_t *db,
+                              const uint32_t *slot, int where);
+/* ocrEventDestroy (ocr-edt.c:101) */
+int ocrgpu_event_destroy(ocrgpu_engine_t *e, uint64_t n, const uint64_t *evt, int where);
+
+/* ---- the worker loop (replaces SCHED_NOTIFY(EDT_READY) -> deque push -> SCHED_GET_WORK ->
+ *      taskExecute -> taskEpilogue, common-scheduler.c:234-313, hc-scheduler-heuristic.c:148-333,
+ *      deque.c:190-265, hc-task.c:1707-2181) for EDTs whose bodies are engine built-ins ---------- */
+/* fire ready EDTs level by level until nothing is ready and no satisfy is in flight */
+int ocrgpu_resolve(ocrgpu_engine_t *e, uint64_t max_levels, ocrgpu_stats_t *stats_out);
+/* snapshot / restore of all mutable dependence state (benchmark loops re-arm a built DAG) */
+int ocrgpu_snapshot(ocrgpu_engine_t *e);
+int ocrgpu_restore(ocrgpu_engine_t *e);
+int ocrgpu_sync(ocrgpu_engine_t *e);
+
+/* ---- results (by engine index = creation order; use ocrgpu_guid_get to go from a guid) -------- */
+/* level_out[i] = level EDT first+i fired at (-1 never), val_out[i] = its HASH fold */
+int ocrgpu_read_edts(ocrgpu_engine_t *e, uint64_t first, uint64_t n, int32_t *level_out, uint64_t *val_out, int where);
+/* OCREVS(code, aux) of explicit events (which = 0) or of the output events of EDTs first.. (which = 1) */
+int ocrgpu_read_events(ocrgpu_engine_t *e, int which, uint64_t first, uint64_t n, uint64_t *state_out, int where);
+/* values of explicit DBs (which = 0) or of the output DBs of EDTs first.. (which = 1; 0 if not created) */
+int ocrgpu_read_dbs(ocrgpu_engine_t *e, int which, uint64_t first, uint64_t n, uint64_t *value_out, int where);
+/* the fired-EDT log: ids_out[0..n_fired) grouped by level, level_start_out[0..n_levels] offsets.
+ * Pass NULL arrays to get the sizes only.                                                      */
+int ocrgpu_read_fired(ocrgpu_engine_t *e, uint64_t *n_fired, uint64_t *n_levels, uint32_t *ids_out,
+                      uint64_t *level_start_out, int where);
+int ocrgpu_get_stats(ocrgpu_engine_t *e, ocrgpu_stats_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1181 @@
+// libocrgpu -- MI355X (gfx950, CDNA4) dependence-resolution engine behind include/ocrgpu.h.
+//
+// What runs where (DESIGN.md has the long form):
+//   HBM-resident SoA state       : EDT pending-slot counters, pre-slot payload words, event state
+//                                  words, CSR waiter rows, the fired-EDT log, the satisfy-record log
+//                                  and the GUID open-addressing table.
+//   k_step (the hot kernel)      : one launch = one phase.  FIRE: pop a level of ready EDTs from the
+//                                  fired log, run their bodies, satisfy their output events in-block
+//                                  and fan the satisfies out edge-balanced over the whole workgroup;
+//                                  EVENTS: the same fan-out for satisfy records queued by chained
+//                                  events / API calls.  The last workgroup to finish decides the next
+//                                  phase on the device, so the host launches ahead and only polls `done`.
+//   wave64 idioms                : ballot + mbcnt prefix for ready-set / record compaction (one global
+//                                  atomic per wave), readfirstlane grouping for latch counters (one
+//                                  atomic per distinct latch per wave), LDS scan for edge balancing.
+// No MFMA: nothing here is a contraction (BASELINE.json north_star).  No CPU fallback: every entry
+// point fails with OCRGPU_ENODEV / OCRGPU_EHIP when there is no usable GPU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "ocrgpu.h"
+#include "ocr_opstream.h"
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t s32;
+
+// ------------------------------------------------------------------------------------------------
+// device-side layout
+// ------------------------------------------------------------------------------------------------
+enum { ST_ABSENT = 0, ST_LIVE = 1, ST_SAT = 2, ST_DESTROYED = 3 };
+enum { MODE_EVENTS = 0, MODE_FIRE = 1 };
+enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_EVENT = 3, ERR_BAD_OP = 4,
+       ERR_Q_OVERFLOW = 5, ERR_LEVEL_OVERFLOW = 6 };
+#define RF_DST_EDT 1u   // record / waiter destination is an EDT pre-slot
+#define RF_MODE_NULL 2u // dependence mode DB_MODE_NULL: the payload is dropped (hc-task.c:1255)
+#define BODY_F_SCRIPT 0x10000u // internal: EDT has a script
+
+struct EvtStatic { u32 row_begin, deg; };           // CSR row of the event's waiters (rebuilt by seal)
+struct EvtMut { u32 state_kind; s32 val; };         // state | kind<<8 ; LATCH counter / persistent payload
+struct EdtStatic { u32 slot_base, depc, body, pad; };
+struct Rec { u32 dst, payload, slot, flags; };      // one pending satisfy: dst = event idx | EDT idx
+struct Script { u32 target, payload, slot, op_kind; }; // op | payload_kind<<8
+
+struct alignas(128) Ctrl {
+    // written by the last workgroup of a launch, read by every workgroup of the next
+    u32 mode, level, r_begin, r_end, q_begin, q_end, done, allow_fire;
+    u32 pad0[24];
+    // atomics (own cache lines)
+    u32 r_tail; u32 pad1[31];
+    u32 q_tail; u32 pad2[31];
+    u32 ticket; u32 log_tail; u32 pad3[30];
+    u64 n_edt_sat, n_evt_sat, n_fired, n_levels; u32 err[8]; u32 pad4[16];
+};
+
+struct Dev {
+    Ctrl *ctrl;
+    // EDTs
+    u32 *edt_pending; EdtStatic *edt_static; u64 *edt_param0; u64 *edt_val; u32 *edt_script_begin, *edt_script_len;
+    u32 *slots;                 // payload word per pre-slot: dbidx+1 (0 = NULL_GUID); bit31 = satisfied (nanny)
+    // events (explicit [0,max_evt) then the output event of EDT e at max_evt+e)
+    EvtStatic *evt_static; EvtMut *evt_mut;
+    u64 *waiters;               // CSR payload: lo = dst | flags<<30 ; hi = absolute slot index | latch slot
+    u32 *log_src; u64 *log_rec; // registration log the CSR is built from
+    // datablocks (explicit [0,max_db) then the output DB of EDT e at max_db+e): {value, tag}
+    ulonglong2 *db;
+    // work lists
+    u32 *fired;                 // fired/ready log, grouped by level
+    u32 *level_start;           // level_start[L] = offset in `fired`
+    Rec *q;                     // satisfy-record log
+    Script *scripts;
+    // GUID table
+    ulonglong2 *gtab; u64 gmask; u32 gshift;
+    // sizes
+    u32 max_edt, max_evt, max_db, max_levels, q_cap, location;
+    u64 max_slots, max_edges, hash_tag_base;
+};
+
+#define TOMB (~0ULL)
+
+__device__ __forceinline__ u64 mkguid(u32 loc, u32 kind, u64 counter) { return ((u64)loc << 54) | ((u64)kind << 49) | counter; }
+__device__ __forceinline__ u32 ghash(const Dev &d, u64 g) { return (u32)((g * 0x9E3779B97F4A7C15ULL) >> d.gshift); }
+
+__device__ void gtab_put(const Dev &d, u64 key, u64 val) {
+    u64 h = ghash(d, key);
+    for (u64 probe = 0; probe <= d.gmask; ++probe, h = (h + 1) & d.gmask) {
+        u64 old = atomicCAS((unsigned long long *)&d.gtab[h].x, 0ULL, (unsigned long long)key);
+        if (old == 0ULL || old == key) { d.gtab[h].y = val; return; }
+    }
+    atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+}
+__device__ u64 gtab_get(const Dev &d, u64 key) {
+    if (key == 0ULL || key >= TOMB - 1) return 0;
+    u64 h = ghash(d, key);
+    for (u64 probe = 0; probe <= d.gmask; ++probe, h = (h + 1) & d.gmask) {
+        ulonglong2 s = d.gtab[h];
+        if (s.x == key) return s.y;
+        if (s.x == 0ULL) return 0;
+    }
+    return 0;
+}
+__device__ void gtab_remove(const Dev &d, u64 key) {
+    u64 h = ghash(d, key);
+    for (u64 probe = 0; probe <= d.gmask; ++probe, h = (h + 1) & d.gmask) {
+        u64 k = d.gtab[h].x;
+        if (k == key) { d.gtab[h].y = 0; d.gtab[h].x = TOMB; return; }
+        if (k == 0ULL) return;
+    }
+}
+// resolve an engine-made guid to its object index, honouring lazy deletion of dead events
+__device__ __forceinline__ bool is_event_kind(u32 k) { return (k & 0x10u) != 0; }
+__device__ u32 evt_kind_to_guid_kind(u32 k) {
+    switch (k) { case OCREVT_ONCE: return OCRGPU_KIND_EVT_ONCE; case OCREVT_IDEM: return OCRGPU_KIND_EVT_IDEM;
+                 case OCREVT_STICKY: return OCRGPU_KIND_EVT_STICKY; case OCREVT_LATCH: return OCRGPU_KIND_EVT_LATCH;
+                 case OCREVT_COUNTED: return OCRGPU_KIND_EVT_COUNTED; default: return OCRGPU_KIND_EVT_CHANNEL; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u32 rank_in(u64 m) { // number of set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+// wave-aggregated append: every lane with pred gets a unique index in [tail, tail+popc); one atomic per wave
+__device__ __forceinline__ u32 wave_append(u32 *tail, bool pred) {
+    u64 m = __ballot(pred);
+    u32 base = 0;
+    if (m) {
+        int leader = __ffsll((long long)m) - 1;
+        if ((int)lane_id() == leader) base = atomicAdd(tail, (u32)__popcll(m));
+        base = __shfl(base, leader);
+    }
+    return base + rank_in(m);
+}
+
+// ------------------------------------------------------------------------------------------------
+// satisfy primitives
+// ------------------------------------------------------------------------------------------------
+// satisfyTaskHc (hc-task.c:1216-1266): store the payload word, count the slot, report "all satisfied"
+template <bool NANNY>
+__device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, u32 edt, u32 abs_slot, u32 payload, u32 flags) {
+    u32 word = (flags & RF_MODE_NULL) ? 0u : payload;
+    if (NANNY) {
+        u32 old = atomicExch(&d.slots[abs_slot], word | 0x80000000u);
+        if (old & 0x80000000u) { atomicAdd(&d.ctrl->err[ERR_DOUBLE_SLOT], 1u); return false; }
+    } else {
+        d.slots[abs_slot] = word;
+    }
+    return atomicSub(&d.edt_pending[edt], 1u) == 1u;
+}
+
+// event.satisfy for ONCE / STICKY / IDEM (hc-event.c:437-465, 569-639).  Returns true when the event
+// fires its waiters with `payload`.  LATCH is handled wave-wide by latch_group().
+__device__ __forceinline__ bool evt_satisfy_simple(const Dev &d, u32 x, u32 kind, u32 payload) {
+    u32 *sk = &d.evt_mut[x].state_kind;
+    if (kind == OCREVT_ONCE) {
+        u32 old = atomicExch(sk, ST_DESTROYED | (kind << 8));
+        if ((old & 0xFF) != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u); return false; }
+        return true;
+    }
+    u32 old = atomicCAS(sk, ST_LIVE | (kind << 8), ST_SAT | (kind << 8));
+    if ((old & 0xFF) == ST_LIVE) { d.evt_mut[x].val = (s32)payload; return true; }
+    if ((old & 0xFF) == ST_SAT) { if (kind == OCREVT_STICKY) atomicAdd(&d.ctrl->err[ERR_STICKY_RESAT], 1u); }
+    else atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
+    return false;
+}
+
+// satisfyEventHcLatch (hc-event.c:812-868) for every latch record held by this wave: lanes that hit the
+// same latch are grouped (readfirstlane + ballot) and ONE atomic applies their summed +1/-1; the group
+// fires iff the counter it leaves is 0 (well-formed programs never pass through 0 before their last op).
+__device__ __forceinline__ bool latch_group(const Dev &d, bool is_latch, u32 x, u32 slot) {
+    bool fire = false;
+    u64 todo = __ballot(is_latch);
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        u32 x0 = __shfl(x, leader);
+        u64 grp = __ballot(is_latch && x == x0) & todo;
+        u64 inc = __ballot(is_latch && x == x0 && slot == OCRLATCH_INCR) & todo;
+        s32 delta = (s32)__popcll(inc) - (s32)__popcll(grp & ~inc);
+        if ((int)lane_id() == leader) {
+            EvtMut *m = &d.evt_mut[x0];
+            if ((m->state_kind & 0xFF) != ST_LIVE) atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
+            else {
+                s32 old = atomicAdd(&m->val, delta);
+                if (old + delta == 0) { m->state_kind = ST_DESTROYED | (OCREVT_LATCH << 8); fire = true; }
+            }
+        }
+        todo &= ~grp;
+    }
+    return fire;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the hot kernel
+// ------------------------------------------------------------------------------------------------
+#define BLK 256
+#define FIRE_CHUNK 64   // EDTs per workgroup pass: ~4 edges each -> ~256 edges for the 256 lanes
+
+struct Seg { u32 row, end_off, payload; }; // end_off = inclusive prefix sum of degrees
+
+// Fan `nseg` fired events out over the whole workgroup, edge-balanced: lane t takes edge t of the
+// concatenated rows (binary search of the LDS prefix sums), so a 10k-waiter row and 63 one-waiter
+// rows cost the same number of passes.
+template <bool NANNY>
+__device__ void fan_out(const Dev &d, Seg *seg, u32 nseg, u32 total, u64 &n_edt_sat, u64 &n_evt_q) {
+    Ctrl *c = d.ctrl;
+    for (u32 base = 0; base < total; base += BLK) {
+        u32 t = base + threadIdx.x;
+        bool act = t < total;
+        bool ready = false, toq = false;
+        u32 dst = 0, slot = 0, payload = 0, flags = 0;
+        if (act) {
+            u32 lo = 0, hi = nseg - 1; // first segment with end_off > t
+            while (lo < hi) { u32 mid = (lo + hi) >> 1; if (seg[mid].end_off > t) hi = mid; else lo = mid + 1; }
+            u32 start = lo ? seg[lo - 1].end_off : 0;
+            u64 w = d.waiters[seg[lo].row + (t - start)];
+            u32 wlo = (u32)w;
+            dst = wlo & 0x3FFFFFFFu; flags = wlo >> 30; slot = (u32)(w >> 32); payload = seg[lo].payload;
+            if (flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, dst, slot, payload, flags); ++n_edt_sat; }
+            else toq = true;
+        }
+        u32 ri = wave_append(&c->r_tail, ready);
+        if (ready) d.fired[ri] = dst;
+        u32 qi = wave_append(&c->q_tail, toq);
+        if (toq) {
+            if (qi < d.q_cap) d.q[qi] = Rec{dst, payload, slot, 0u};
+            else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
+            ++n_evt_q;
+        }
+    }
+}
+
+// block-wide inclusive scan of one u32 per thread (BLK = 256 = 4 waves), result in LDS-free registers
+__device__ __forceinline__ u32 block_inclusive_scan(u32 v, u32 *wave_sums, u32 &total) {
+    u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { u32 n = __shfl_up(v, o); if (lane >= (u32)o) v += n; }
+    if (lane == 63) wave_sums[wid] = v;
+    __syncthreads();
+    u32 add = 0;
+    for (u32 w = 0; w < wid; ++w) add += wave_sums[w];
+    total = wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    __syncthreads();
+    return v + add;
+}
+
+template <bool NANNY>
+__global__ __launch_bounds__(BLK) void k_step(Dev d) {
+    __shared__ Seg seg[BLK];
+    __shared__ u32 wave_sums[4];
+    Ctrl *c = d.ctrl;
+    if (c->done) return;
+    const u32 mode = c->mode, level = c->level;
+    const u32 r_begin = c->r_begin, r_end = c->r_end, q_begin = c->q_begin, q_end = c->q_end;
+    u64 n_edt_sat = 0, n_evt_sat = 0, n_fired = 0, n_dummy = 0;
+
+    if (mode == MODE_FIRE) {
+        // ---- taskExecute + taskEpilogue for one level (hc-task.c:1864-2181, 1707-1862) ----
+        for (u32 cb = r_begin + blockIdx.x * FIRE_CHUNK; cb < r_end; cb += gridDim.x * FIRE_CHUNK) {
+            u32 deg = 0; Seg s = {0, 0, 0};
+            u32 i = cb + threadIdx.x;
+            if (threadIdx.x < FIRE_CHUNK && i < r_end) {
+                u32 e = d.fired[i];
+                EdtStatic es = d.edt_static[e];
+                u64 id = d.edt_param0[e];
+                u64 v = ocrops_hash_init(id);
+                const u32 *sl = d.slots + es.slot_base;
+                u32 p0 = 0;
+                for (u32 k = 0; k < es.depc; ++k) {
+                    u32 p = sl[k] & 0x7FFFFFFFu;
+                    if (k == 0) p0 = p;
+                    u64 pv = 0, tagp1 = 0;
+                    if (p) { ulonglong2 b = d.db[p - 1]; pv = b.x; tagp1 = b.y + 1; }
+                    v = ocrops_hash_step(v, k, pv, tagp1);
+                }
+                d.edt_val[e] = v;
+                u32 ret = 0;
+                u32 kind = OCRBODY_KIND(es.body);
+                if (kind == OCRBODY_HASH) { ret = d.max_db + e + 1; d.db[ret - 1] = make_ulonglong2(v, d.hash_tag_base + id); }
+                else if (kind == OCRBODY_FWD0) ret = p0;
+                ++n_fired;
+                if (es.body & BODY_F_SCRIPT) { // the body's own ocrEventSatisfySlot / ocrEventDestroy calls
+                    u32 sb = d.edt_script_begin[e], sn = d.edt_script_len[e];
+                    for (u32 k = 0; k < sn; ++k) {
+                        Script sc = d.scripts[sb + k];
+                        u32 op = sc.op_kind & 0xFF, pk = sc.op_kind >> 8;
+                        if (op == OCRGPU_SOP_SATISFY) {
+                            u32 pay = pk == OCRGPU_PAY_GUID ? sc.payload : pk == OCRGPU_PAY_OUTDB ? d.max_db + e + 1
+                                    : pk == OCRGPU_PAY_DEPV ? (sl[sc.payload] & 0x7FFFFFFFu) : 0u;
+                            u32 qi = atomicAdd(&c->q_tail, 1u);
+                            if (qi < d.q_cap) d.q[qi] = Rec{sc.target, pay, sc.slot, 0u};
+                            else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
+                        } else { // ocrEventDestroy
+                            u32 old = atomicExch(&d.evt_mut[sc.target].state_kind, (u32)ST_DESTROYED);
+                            if ((old & 0xFF) != ST_LIVE && (old & 0xFF) != ST_SAT) atomicAdd(&c->err[ERR_DEAD_EVENT], 1u);
+                        }
+                    }
+                }
+                if (es.body & OCRBODY_F_OUTEVT) { // epilogue: satisfy the ONCE output event with the returned guid
+                    u32 x = d.max_evt + e;
+                    ++n_evt_sat;
+                    if (evt_satisfy_simple(d, x, OCREVT_ONCE, ret)) {
+                        EvtStatic st = d.evt_static[x];
+                        deg = st.deg; s.row = st.row_begin; s.payload = ret;
+                    }
+                }
+            }
+            u32 total;
+            u32 incl = block_inclusive_scan(deg, wave_sums, total);
+            s.end_off = incl;
+            seg[threadIdx.x] = s;
+            __syncthreads();
+            if (total) fan_out<NANNY>(d, seg, BLK, total, n_edt_sat, n_dummy);
+            __syncthreads();
+        }
+    } else {
+        // ---- queued satisfies: API calls, chained events, direct EDT pre-slot satisfies ----
+        for (u32 cb = q_begin + blockIdx.x * BLK; cb < q_end; cb += gridDim.x * BLK) {
+            u32 deg = 0; Seg s = {0, 0, 0};
+            u32 i = cb + threadIdx.x;
+            bool act = i < q_end;
+            Rec r = {0, 0, 0, 0};
+            bool ready = false, is_latch = false;
+            u32 kind = 0;
+            if (act) {
+                r = d.q[i];
+                if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, r.dst, r.slot, r.payload, r.flags); ++n_edt_sat; }
+                else { kind = (d.evt_mut[r.dst].state_kind >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
+            }
+            u32 ri = wave_append(&c->r_tail, ready);
+            if (ready) d.fired[ri] = r.dst;
+            bool fire = latch_group(d, is_latch, r.dst, r.slot);
+            if (act && !(r.flags & RF_DST_EDT) && !is_latch) {
+                if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM) fire = evt_satisfy_simple(d, r.dst, kind, r.payload);
+                else atomicAdd(&c->err[(d.evt_mut[r.dst].state_kind & 0xFF) == ST_ABSENT ? ERR_BAD_OP : ERR_DEAD_EVENT], 1u);
+            }
+            if (fire) { EvtStatic st = d.evt_static[r.dst]; deg = st.deg; s.row = st.row_begin; s.payload = r.payload; }
+            u32 total;
+            u32 incl = block_inclusive_scan(deg, wave_sums, total);
+            s.end_off = incl;
+            seg[threadIdx.x] = s;
+            __syncthreads();
+            if (total) fan_out<NANNY>(d, seg, BLK, total, n_edt_sat, n_dummy);
+            __syncthreads();
+        }
+    }
+
+    // ---- statistics: one atomic per wave per counter ----
+    for (int o = 32; o > 0; o >>= 1) {
+        n_edt_sat += __shfl_down(n_edt_sat, o); n_evt_sat += __shfl_down(n_evt_sat, o); n_fired += __shfl_down(n_fired, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_edt_sat) atomicAdd((unsigned long long *)&c->n_edt_sat, (unsigned long long)n_edt_sat);
+        if (n_evt_sat) atomicAdd((unsigned long long *)&c->n_evt_sat, (unsigned long long)n_evt_sat);
+        if (n_fired) atomicAdd((unsigned long long *)&c->n_fired, (unsigned long long)n_fired);
+    }
+    // ---- the last workgroup to finish picks the next phase (scheduler "get work", on the device) ----
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        u32 t = atomicAdd(&c->ticket, 1u);
+        if (t == gridDim.x - 1) {
+            c->ticket = 0;
+            u32 q_tail = atomicAdd(&c->q_tail, 0u), r_tail = atomicAdd(&c->r_tail, 0u);
+            if (q_tail > d.q_cap) q_tail = d.q_cap;
+            if (q_tail > q_end) { c->mode = MODE_EVENTS; c->q_begin = q_end; c->q_end = q_tail; }
+            else if (c->allow_fire && r_tail > r_end) {
+                u32 nl = level + 1; // level starts at 0xFFFFFFFF ("main" = level -1)
+                c->mode = MODE_FIRE; c->level = nl; c->q_begin = q_end;
+                c->r_begin = r_end; c->r_end = r_tail;
+                if (nl < d.max_levels) { d.level_start[nl] = r_end; d.level_start[nl + 1] = r_tail; }
+                else atomicAdd(&c->err[ERR_LEVEL_OVERFLOW], 1u);
+                c->n_levels = (u64)nl + 1;
+            } else { c->done = 1; c->q_begin = q_end; }
+        }
+    }
+}
+
+// Decide the first phase of a drain / resolve (single thread).
+__global__ void k_begin(Dev d, u32 allow_fire) {
+    Ctrl *c = d.ctrl;
+    c->allow_fire = allow_fire; c->ticket = 0;
+    u32 q_tail = c->q_tail, r_tail = c->r_tail;
+    if (q_tail > d.q_cap) q_tail = d.q_cap;
+    c->q_end = c->q_begin; // nothing in flight
+    if (q_tail > c->q_begin) { c->mode = MODE_EVENTS; c->q_end = q_tail; c->done = 0; }
+    else if (allow_fire && r_tail > c->r_end) {
+        u32 nl = c->level + 1; // level starts at 0xFFFFFFFF
+        c->mode = MODE_FIRE; c->level = nl; c->r_begin = c->r_end; c->r_end = r_tail; c->done = 0;
+        if (nl < d.max_levels) { d.level_start[nl] = c->r_begin; d.level_start[nl + 1] = r_tail; }
+        else c->err[ERR_LEVEL_OVERFLOW]++;
+        c->n_levels = (u64)nl + 1;
+    } else c->done = 1;
+}
+// After a drain: if the record log is fully consumed, rewind it (keeps q_cap small).
+__global__ void k_end(Dev d) {
+    Ctrl *c = d.ctrl;
+    if (c->done && c->q_begin >= c->q_tail) { c->q_begin = c->q_end = 0; c->q_tail = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// construction kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_event_create(Dev d, u64 n, const u32 *kind, const s32 *arg, u32 first_idx, u64 first_counter, u64 *guids_out) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 k = kind[i], x = first_idx + (u32)i;
+    d.evt_mut[x] = EvtMut{ST_LIVE | (k << 8), k == OCREVT_LATCH ? arg[i] : 0};
+    d.evt_static[x] = EvtStatic{0, 0};
+    u64 g = mkguid(d.location, evt_kind_to_guid_kind(k), first_counter + i);
+    gtab_put(d, g, (u64)x + 1);
+    guids_out[i] = g;
+}
+__global__ void k_db_create(Dev d, u64 n, const u64 *value, const u64 *tag, u32 first_idx, u64 first_counter, u64 *guids_out) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 x = first_idx + (u32)i;
+    d.db[x] = make_ulonglong2(value[i], tag ? tag[i] : (u64)x);
+    u64 g = mkguid(d.location, OCRGPU_KIND_DB, first_counter + i);
+    gtab_put(d, g, (u64)x + 1);
+    guids_out[i] = g;
+}
+// slot_base[] already holds the exclusive scan of depc (+ slots in use)
+__global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, const u64 *param0, const u32 *slot_base,
+                             u32 first_idx, u64 first_counter, u64 *guids_out, u64 *outevt_out, u64 *outdb_out) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 e = first_idx + (u32)i, dc = depc[i], b = body[i] & 0xFFFFu;
+    d.edt_static[e] = EdtStatic{slot_base[i], dc, b, 0};
+    d.edt_pending[e] = dc;
+    d.edt_param0[e] = param0 ? param0[i] : (u64)e;
+    d.edt_val[e] = 0;
+    u64 g = mkguid(d.location, OCRGPU_KIND_EDT, first_counter + 3 * i);
+    gtab_put(d, g, (u64)e + 1);
+    guids_out[i] = g;
+    u64 ge = 0;
+    if (b & OCRBODY_F_OUTEVT) { // ONCE output event (hc-task.c:940-959)
+        u32 x = d.max_evt + e;
+        d.evt_mut[x] = EvtMut{ST_LIVE | (OCREVT_ONCE << 8), 0};
+        d.evt_static[x] = EvtStatic{0, 0};
+        ge = mkguid(d.location, OCRGPU_KIND_EVT_ONCE, first_counter + 3 * i + 1);
+        gtab_put(d, ge, (u64)x + 1);
+    }
+    if (outevt_out) outevt_out[i] = ge;
+    u64 gd = mkguid(d.location, OCRGPU_KIND_DB, first_counter + 3 * i + 2);
+    gtab_put(d, gd, (u64)(d.max_db + e) + 1);
+    if (outdb_out) outdb_out[i] = gd;
+    if (dc == 0) { u32 ri = atomicAdd(&d.ctrl->r_tail, 1u); d.fired[ri] = e; } // fires at creation (hc-task.c:1129-1134)
+}
+
+__device__ __forceinline__ void q_push(const Dev &d, Rec r) {
+    u32 qi = atomicAdd(&d.ctrl->q_tail, 1u);
+    if (qi < d.q_cap) d.q[qi] = r; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+}
+__device__ __forceinline__ void bad_op(const Dev &d) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); }
+
+// resolve a destination guid into (idx, is_edt, abs slot)
+__device__ bool resolve_dst(const Dev &d, u64 g, u32 slot, u32 &idx, bool &is_edt, u32 &slot_out) {
+    u64 v = gtab_get(d, g);
+    if (!v) return false;
+    u32 k = OCRGPU_GUID_KIND(g);
+    idx = (u32)(v - 1);
+    if (k == OCRGPU_KIND_EDT) {
+        EdtStatic es = d.edt_static[idx];
+        if (slot >= es.depc) return false;
+        is_edt = true; slot_out = es.slot_base + slot; return true;
+    }
+    if (!is_event_kind(k)) return false;
+    is_edt = false; slot_out = slot; return true;
+}
+
+// ocrAddDependence classification (hc-policy.c:2857-3074)
+__global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 s = src[i];
+    u32 didx, dslot; bool d_edt;
+    if (!resolve_dst(d, dst[i], slot[i], didx, d_edt, dslot)) { bad_op(d); return; }
+    u32 mnull = (d_edt && mode[i] == OCRMODE_NULL) ? RF_MODE_NULL : 0u;
+    u32 dflag = d_edt ? RF_DST_EDT : 0u;
+    if (s == OCRGPU_NULL_GUID) { q_push(d, Rec{didx, 0u, dslot, dflag}); return; } // == satisfy(dst, slot, NULL)
+    u64 sv = gtab_get(d, s);
+    u32 sk = OCRGPU_GUID_KIND(s);
+    if (!sv) { atomicAdd(&d.ctrl->err[is_event_kind(sk) ? ERR_LATE_WAITER : ERR_BAD_OP], 1u); return; }
+    if (sk == OCRGPU_KIND_DB) { q_push(d, Rec{didx, (u32)sv, dslot, dflag | mnull}); return; } // mode recorded, then satisfy
+    if (!is_event_kind(sk)) { bad_op(d); return; }
+    u32 x = (u32)(sv - 1);
+    EvtMut m = d.evt_mut[x];
+    u32 st = m.state_kind & 0xFF;
+    if (st == ST_SAT) { q_push(d, Rec{didx, (u32)m.val, dslot, dflag | mnull}); return; } // registerWaiterEventHcPersist :1143-1155
+    if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }    // registerWaiterEventHc :1078-1083
+    u32 li = atomicAdd(&d.ctrl->log_tail, 1u);
+    if (li >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+    d.log_src[li] = x;
+    d.log_rec[li] = ((u64)dslot << 32) | (u64)(didx | ((dflag | mnull) << 30));
+}
+
+__global__ void k_satisfy(Dev d, u64 n, const u64 *evt, const u64 *db, const u32 *slot) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 g = evt[i];
+    if (g == OCRGPU_NULL_GUID) return; // ocrEventSatisfy(NULL_GUID, ..) is a no-op (ocr-edt.c:171)
+    u32 didx, dslot; bool d_edt;
+    if (!resolve_dst(d, g, slot[i], didx, d_edt, dslot)) { bad_op(d); return; }
+    u32 pay = 0;
+    if (db[i] != OCRGPU_NULL_GUID) { u64 v = gtab_get(d, db[i]); if (!v || OCRGPU_GUID_KIND(db[i]) != OCRGPU_KIND_DB) { bad_op(d); return; } pay = (u32)v; }
+    q_push(d, Rec{didx, pay, dslot, d_edt ? RF_DST_EDT : 0u});
+}
+
+__global__ void k_evt_destroy(Dev d, u64 n, const u64 *evt) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 v = gtab_get(d, evt[i]);
+    if (!v || !is_event_kind(OCRGPU_GUID_KIND(evt[i]))) { bad_op(d); return; }
+    u32 old = atomicExch(&d.evt_mut[v - 1].state_kind, (u32)ST_DESTROYED);
+    if ((old & 0xFF) != ST_LIVE && (old & 0xFF) != ST_SAT) atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
+}
+
+__global__ void k_set_scripts(Dev d, u64 n, const u64 *edt, const u32 *begin, const u32 *len, u32 script_base) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 v = gtab_get(d, edt[i]);
+    if (!v || OCRGPU_GUID_KIND(edt[i]) != OCRGPU_KIND_EDT) { bad_op(d); return; }
+    u32 e = (u32)(v - 1);
+    d.edt_script_begin[e] = script_base + begin[i]; d.edt_script_len[e] = len[i];
+    if (len[i]) d.edt_static[e].body |= BODY_F_SCRIPT;
+}
+__global__ void k_script_ops(Dev d, u64 n, const ocrgpu_script_op_t *ops, u32 script_base) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ocrgpu_script_op_t o = ops[i];
+    u64 v = gtab_get(d, o.target);
+    if (!v || !is_event_kind(OCRGPU_GUID_KIND(o.target))) { bad_op(d); v = 1; }
+    u32 pay = (u32)o.payload;
+    if (o.payload_kind == OCRGPU_PAY_GUID) { u64 pv = gtab_get(d, o.payload); if (!pv) bad_op(d); pay = (u32)pv; }
+    d.scripts[script_base + i] = Script{(u32)(v - 1), pay, o.slot, (u32)o.op | ((u32)o.payload_kind << 8)};
+}
+
+// ---- CSR (re)build from the registration log: count -> scan -> fill --------------------------------
+__global__ void k_csr_clear(Dev d, u32 n_evt_total) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_evt_total) d.evt_static[i].deg = 0;
+}
+__global__ void k_csr_count(Dev d) {
+    u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        u32 x = d.log_src[i];
+        if ((d.evt_mut[x].state_kind & 0xFF) == ST_LIVE) atomicAdd(&d.evt_static[x].deg, 1u);
+    }
+}
+__global__ void k_csr_gather_deg(Dev d, u32 n, u32 *deg) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) deg[i] = d.evt_static[i].deg;
+}
+__global__ void k_csr_set_rows(Dev d, u32 n, const u32 *row, u32 *cursor) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { d.evt_static[i].row_begin = row[i]; cursor[i] = row[i]; }
+}
+__global__ void k_csr_fill(Dev d, u32 *cursor) {
+    u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        u32 x = d.log_src[i];
+        if ((d.evt_mut[x].state_kind & 0xFF) == ST_LIVE) d.waiters[atomicAdd(&cursor[x], 1u)] = d.log_rec[i];
+    }
+}
+
+// ---- exclusive scan (u32), 1024 elements per workgroup, recursive over the partials -------------------
+#define SCAN_ITEMS 4
+__global__ __launch_bounds__(BLK) void k_scan_block(const u32 *in, u32 *out, u32 *partial, u64 n, u32 add0) {
+    __shared__ u32 ws[4];
+    u64 base = (u64)blockIdx.x * (BLK * SCAN_ITEMS) + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 v[SCAN_ITEMS], sum = 0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; sum += v[k]; }
+    u32 total;
+    u32 incl = block_inclusive_scan(sum, ws, total);
+    u32 run = incl - sum + add0;
+    for (int k = 0; k < SCAN_ITEMS; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 0 && partial) partial[blockIdx.x] = total;
+}
+__global__ void k_scan_add(u32 *out, const u32 *partial_scanned, u64 n) {
+    u64 i = (u64)blockIdx.x * (BLK * SCAN_ITEMS) + threadIdx.x;
+    u32 add = partial_scanned[blockIdx.x];
+    for (int k = 0; k < SCAN_ITEMS; ++k, i += BLK) if (i < n) out[i] += add;
+}
+__global__ void k_last_sum(const u32 *in, const u32 *scanned, u64 n, u32 *out) { if (n) *out = scanned[n - 1] + in[n - 1]; else *out = 0; }
+
+// ---- GUID provider kernels ----------------------------------------------------------------------------------
+__global__ void k_guid_reserve(Dev d, u32 kind, u64 n, u64 first_counter, u64 *out) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mkguid(d.location, kind, first_counter + i);
+}
+__global__ void k_guid_put(Dev d, u64 n, const u64 *g, const u64 *v) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) { if (g[i] == 0 || g[i] >= TOMB - 1 || v[i] == 0) bad_op(d); else gtab_put(d, g[i], v[i]); }
+}
+__global__ void k_guid_get(Dev d, u64 n, const u64 *g, u64 *v) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 r = gtab_get(d, g[i]);
+    // lazy deletion: an engine-made event guid stops resolving once the event is destroyed
+    // (the reference's destructEventHc -> PD_MSG_GUID_DESTROY -> releaseGuid, hc-event.c:185-242)
+    if (r && OCRGPU_GUID_LOCATION(g[i]) == d.location && is_event_kind(OCRGPU_GUID_KIND(g[i])) && r <= (u64)d.max_evt + d.max_edt) {
+        u32 st = d.evt_mut[r - 1].state_kind & 0xFF;
+        if (st == ST_DESTROYED || st == ST_ABSENT) r = 0;
+    }
+    v[i] = r;
+}
+__global__ void k_guid_remove(Dev d, u64 n, const u64 *g) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n && g[i] != 0 && g[i] < TOMB - 1) gtab_remove(d, g[i]);
+}
+
+// ---- result readback ------------------------------------------------------------------------------------
+__global__ void k_fill_i32(s32 *p, u64 n, s32 v) { u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void k_levels(Dev d, u64 first, u64 n, s32 *level_out) {
+    u32 nf = d.ctrl->r_end, nl = (u32)d.ctrl->n_levels;
+    if (nl > d.max_levels) nl = d.max_levels;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x) {
+        u32 e = d.fired[i];
+        if (e < first || e >= first + n) continue;
+        u32 lo = 0, hi = nl; // last level whose start <= i
+        while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (d.level_start[mid] <= i) lo = mid; else hi = mid; }
+        level_out[e - first] = (s32)lo;
+    }
+}
+__global__ void k_read_vals(Dev d, u64 first, u64 n, const s32 *level, u64 *val_out) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) val_out[i] = level[i] >= 0 ? d.edt_val[first + i] : 0; // stale after a restore unless fired
+}
+__global__ void k_read_events(Dev d, u32 first, u64 n, u64 *out) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    EvtMut m = d.evt_mut[first + i];
+    u32 st = m.state_kind & 0xFF, kind = (m.state_kind >> 8) & 0xFF;
+    u64 r;
+    if (st == ST_ABSENT) r = OCREVS(OCREVS_ABSENT, 0);
+    else if (st == ST_DESTROYED) r = OCREVS(OCREVS_DESTROYED, 0);
+    else if (st == ST_SAT) r = OCREVS(OCREVS_LIVE_SAT, m.val ? (u32)(d.db[m.val - 1].y + 1) : 0u);
+    else r = OCREVS(OCREVS_LIVE_UNSAT, kind == OCREVT_LATCH ? (u32)m.val : 0u);
+    out[i] = r;
+}
+__global__ void k_read_dbs(Dev d, u32 first, u64 n, const s32 *level, u32 first_edt, u64 *out) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (level) { // output DBs exist once their EDT has fired with a HASH body
+        bool live = level[i] >= 0 && OCRBODY_KIND(d.edt_static[first_edt + i].body) == OCRBODY_HASH;
+        out[i] = live ? d.db[first + i].x : 0;
+    } else out[i] = d.db[first + i].x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+#define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); return OCRGPU_EHIP; } } while (0)
+#define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
+
+struct Snapshot { u32 *edt_pending; EvtMut *evt_mut; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt_explicit; bool valid; };
+
+struct ocrgpu_engine {
+    int device; hipStream_t stream; ocrgpu_config_t cfg; Dev d;
+    std::vector<void *> allocs;
+    // host mirrors
+    u32 n_edt, n_evt, n_db; u64 n_slots, n_script; u64 counter; u64 edges_upper;
+    bool csr_dirty; u32 q_cap;
+    // staging
+    char *stage_dev; size_t stage_dev_cap, stage_dev_off; char *stage_host; size_t stage_host_cap;
+    u32 *tmp_a, *tmp_b, *tmp_c; // scan temporaries sized for max(max_edt, n_evt_total)
+    u32 *scan_partials; u64 scan_partials_cap;
+    Snapshot snap;
+    hipEvent_t ev0, ev1; bool have_events;
+    ocrgpu_stats_t last; u64 launches_total, step_ns_total;
+    u32 *pinned_done;
+};
+
+static int dalloc(ocrgpu_engine *e, void **p, size_t bytes, bool zero = true) {
+    if (bytes == 0) bytes = 16;
+    HIPCHK(hipMalloc(p, bytes));
+    e->allocs.push_back(*p);
+    if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, e->stream));
+    return 0;
+}
+#define DALLOC(ptr, T, count) do { int _r = dalloc(e, (void **)&(ptr), sizeof(T) * (size_t)(count)); if (_r) return _r; } while (0)
+
+static inline u32 nblk(u64 n, u32 b = 256) { return (u32)((n + b - 1) / b); }
+
+// staging arena: host arrays -> device copies for the duration of one call
+static int stage_reset(ocrgpu_engine *e) { e->stage_dev_off = 0; return 0; }
+static int stage_reserve(ocrgpu_engine *e, size_t bytes) {
+    if (bytes <= e->stage_dev_cap) return 0;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->stage_dev) HIPCHK(hipFree(e->stage_dev));
+    size_t cap = bytes + (bytes >> 2) + 4096;
+    HIPCHK(hipMalloc((void **)&e->stage_dev, cap));
+    e->stage_dev_cap = cap;
+    return 0;
+}
+template <typename T> static int stage_in(ocrgpu_engine *e, const T *p, u64 n, int where, const T **out) {
+    if (p == nullptr) { *out = nullptr; return 0; }
+    if (where == OCRGPU_DEVICE) { *out = p; return 0; }
+    size_t bytes = (sizeof(T) * n + 255) & ~(size_t)255;
+    if (e->stage_dev_off + bytes > e->stage_dev_cap) FAIL(OCRGPU_ENOMEM, "staging arena too small (internal)");
+    T *dp = (T *)(e->stage_dev + e->stage_dev_off);
+    e->stage_dev_off += bytes;
+    HIPCHK(hipMemcpyAsync(dp, p, sizeof(T) * n, hipMemcpyHostToDevice, e->stream));
+    *out = dp;
+    return 0;
+}
+template <typename T> static int stage_out_alloc(ocrgpu_engine *e, T *p, u64 n, int where, T **out) {
+    if (p == nullptr) { *out = nullptr; return 0; }
+    if (where == OCRGPU_DEVICE) { *out = p; return 0; }
+    size_t bytes = (sizeof(T) * n + 255) & ~(size_t)255;
+    if (e->stage_dev_off + bytes > e->stage_dev_cap) FAIL(OCRGPU_ENOMEM, "staging arena too small (internal)");
+    *out = (T *)(e->stage_dev + e->stage_dev_off);
+    e->stage_dev_off += bytes;
+    return 0;
+}
+template <typename T> static int stage_out_copy(ocrgpu_engine *e, T *host, const T *dev, u64 n, int where) {
+    if (host == nullptr || where == OCRGPU_DEVICE) return 0;
+    HIPCHK(hipMemcpyAsync(host, dev, sizeof(T) * n, hipMemcpyDeviceToHost, e->stream));
+    return 0;
+}
+static size_t rup(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// exclusive scan of in[0..n) into out (+add0); total (optional, device u32) receives the sum
+static int scan_u32(ocrgpu_engine *e, const u32 *in, u32 *out, u64 n, u32 add0, u32 *total_dev) {
+    if (n == 0) { if (total_dev) HIPCHK(hipMemsetAsync(total_dev, 0, 4, e->stream)); return 0; }
+    const u64 per = BLK * SCAN_ITEMS;
+    u64 nb = (n + per - 1) / per;
+    if (nb == 1) {
+        k_scan_block<<<1, BLK, 0, e->stream>>>(in, out, nullptr, n, add0);
+    } else {
+        // partials live in scan_partials, levels packed one after the other
+        u64 need = 0; for (u64 m = nb; ; m = (m + per - 1) / per) { need += 2 * m; if (m == 1) break; }
+        if (need > e->scan_partials_cap) {
+            HIPCHK(hipStreamSynchronize(e->stream));
+            if (e->scan_partials) HIPCHK(hipFree(e->scan_partials));
+            HIPCHK(hipMalloc((void **)&e->scan_partials, need * 4 + 1024));
+            e->scan_partials_cap = need + 256;
+        }
+        u32 *part = e->scan_partials, *part_scanned = part + nb;
+        k_scan_block<<<(u32)nb, BLK, 0, e->stream>>>(in, out, part, n, add0);
+        // scan the partials (recursion on a sub-range of the same buffer)
+        struct Tmp { u32 *buf; u64 cap; } save = {e->scan_partials, e->scan_partials_cap};
+        e->scan_partials = part_scanned + nb; e->scan_partials_cap = save.cap - 2 * nb;
+        int r = scan_u32(e, part, part_scanned, nb, 0, nullptr);
+        e->scan_partials = save.buf; e->scan_partials_cap = save.cap;
+        if (r) return r;
+        k_scan_add<<<(u32)nb, BLK, 0, e->stream>>>(out, part_scanned, n);
+    }
+    if (total_dev) k_last_sum<<<1, 1, 0, e->stream>>>(in, out, n, total_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ocrgpu_abi_version(void) { return 1; }
+extern "C" const char *ocrgpu_last_error(void) { return g_err; }
+
+extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_config_t *cfg) {
+    if (!out || !cfg) FAIL(OCRGPU_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(OCRGPU_ENODEV, "no HIP device: libocrgpu has no CPU path");
+    if (device < 0 || device >= ndev) FAIL(OCRGPU_EINVAL, "device %d out of range (%d devices)", device, ndev);
+    if ((u64)cfg->max_edt >= (1u << 30) || (u64)cfg->max_evt + cfg->max_edt >= (1u << 30)) FAIL(OCRGPU_EINVAL, "at most 2^30 objects per partition");
+    if (cfg->max_edges >= (1ull << 32) || cfg->max_slots >= (1ull << 31)) FAIL(OCRGPU_EINVAL, "max_edges < 2^32 and max_slots < 2^31 per partition");
+    if (cfg->location >= 1024) FAIL(OCRGPU_EINVAL, "location must fit GUID_PROVIDER_LOCID_SIZE=10 bits");
+    HIPCHK(hipSetDevice(device));
+    ocrgpu_engine *e = new ocrgpu_engine();
+    e->device = device; e->stream = 0; e->cfg = *cfg;
+    e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
+    e->csr_dirty = false; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
+    e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->have_events = false;
+    e->launches_total = 0; e->step_ns_total = 0; memset(&e->last, 0, sizeof e->last);
+    Dev &d = e->d; memset(&d, 0, sizeof d);
+    d.max_edt = cfg->max_edt; d.max_evt = cfg->max_evt; d.max_db = cfg->max_db; d.location = cfg->location;
+    d.max_slots = cfg->max_slots ? cfg->max_slots : 1; d.max_edges = cfg->max_edges ? cfg->max_edges : 1;
+    d.max_levels = cfg->max_levels ? cfg->max_levels : (1u << 20);
+    u64 n_evt_total = (u64)cfg->max_evt + cfg->max_edt, n_db_total = (u64)cfg->max_db + cfg->max_edt;
+    u64 q_cap = 2 * (n_evt_total + cfg->max_edt) + 4096; if (q_cap > 0xFFFFFFF0ull) q_cap = 0xFFFFFFF0ull;
+    d.q_cap = (u32)q_cap; e->q_cap = (u32)q_cap;
+    u64 objs = n_evt_total + n_db_total + cfg->max_edt;
+    u64 gs = cfg->guid_slots ? cfg->guid_slots : 2 * objs;
+    u64 cap = 1024; u32 lg = 10; while (cap < gs) { cap <<= 1; ++lg; }
+    d.gmask = cap - 1; d.gshift = 64 - lg;
+#define TRY(x) do { int _r = (x); if (_r) { ocrgpu_fini(e); return _r; } } while (0)
+    TRY(dalloc(e, (void **)&d.ctrl, sizeof(Ctrl)));
+    TRY(dalloc(e, (void **)&d.edt_pending, 4 * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&d.edt_static, sizeof(EdtStatic) * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&d.edt_param0, 8 * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&d.edt_val, 8 * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&d.edt_script_begin, 4 * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&d.edt_script_len, 4 * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&d.slots, 4 * (size_t)d.max_slots));
+    TRY(dalloc(e, (void **)&d.evt_static, sizeof(EvtStatic) * (size_t)n_evt_total));
+    TRY(dalloc(e, (void **)&d.evt_mut, sizeof(EvtMut) * (size_t)n_evt_total));
+    TRY(dalloc(e, (void **)&d.waiters, 8 * (size_t)d.max_edges));
+    TRY(dalloc(e, (void **)&d.log_src, 4 * (size_t)d.max_edges));
+    TRY(dalloc(e, (void **)&d.log_rec, 8 * (size_t)d.max_edges));
+    TRY(dalloc(e, (void **)&d.db, 16 * (size_t)n_db_total));
+    TRY(dalloc(e, (void **)&d.fired, 4 * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&d.level_start, 4 * ((size_t)d.max_levels + 2)));
+    TRY(dalloc(e, (void **)&d.q, sizeof(Rec) * (size_t)q_cap, false));
+    TRY(dalloc(e, (void **)&d.scripts, sizeof(Script) * ((size_t)cfg->max_edt + 1024)));
+    TRY(dalloc(e, (void **)&d.gtab, 16 * (size_t)cap));
+    u64 tmpn = n_evt_total > cfg->max_edt ? n_evt_total : cfg->max_edt;
+    TRY(dalloc(e, (void **)&e->tmp_a, 4 * (size_t)(tmpn + 4)));
+    TRY(dalloc(e, (void **)&e->tmp_b, 4 * (size_t)(tmpn + 4)));
+    TRY(dalloc(e, (void **)&e->tmp_c, 4 * (size_t)(tmpn + 4)));
+    // ctrl.level starts at -1 (main-program satisfies are "level -1")
+    Ctrl h; memset(&h, 0, sizeof h); h.level = 0xFFFFFFFFu; h.done = 1;
+    if (hipMemcpyAsync(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice, e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "ctrl init failed"); }
+    if (hipHostMalloc((void **)&e->pinned_done, 64) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
+    if (cfg->flags & OCRGPU_F_TIMING) { if (hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess) e->have_events = true; }
+    if (hipStreamSynchronize(e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "init sync failed"); }
+#undef TRY
+    *out = e;
+    return 0;
+}
+
+extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
+    if (!e) return 0;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->stage_dev) (void)hipFree(e->stage_dev);
+    if (e->scan_partials) (void)hipFree(e->scan_partials);
+    if (e->snap.valid) { (void)hipFree(e->snap.edt_pending); (void)hipFree(e->snap.evt_mut); (void)hipFree(e->snap.fired); (void)hipFree(e->snap.ctrl); }
+    if (e->pinned_done) (void)hipHostFree(e->pinned_done);
+    if (e->have_events) { (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1); }
+    delete e;
+    return 0;
+}
+
+extern "C" int ocrgpu_set_stream(ocrgpu_engine_t *e, void *s) { if (!e) FAIL(OCRGPU_EINVAL, "null engine"); e->stream = (hipStream_t)s; return 0; }
+extern "C" int ocrgpu_sync(ocrgpu_engine_t *e) { if (!e) FAIL(OCRGPU_EINVAL, "null engine"); HIPCHK(hipStreamSynchronize(e->stream)); return 0; }
+extern "C" int ocrgpu_set_hash_tag_base(ocrgpu_engine_t *e, u64 b) { if (!e) FAIL(OCRGPU_EINVAL, "null engine"); e->d.hash_tag_base = b; return 0; }
+
+#define ENTER(e) do { if (!(e)) FAIL(OCRGPU_EINVAL, "null engine"); HIPCHK(hipSetDevice((e)->device)); stage_reset(e); } while (0)
+
+// ---- CSR seal ---------------------------------------------------------------------------------------------
+static int seal(ocrgpu_engine *e) {
+    if (!e->csr_dirty) return 0;
+    Dev &d = e->d;
+    u32 n_evt_total = d.max_evt + d.max_edt; // rows exist for every possible event index
+    // only indices in use matter: explicit [0,n_evt) and output events [max_evt, max_evt+n_edt)
+    u32 used = d.max_evt + e->n_edt;
+    (void)n_evt_total;
+    k_csr_clear<<<nblk(used), 256, 0, e->stream>>>(d, used);
+    u32 g = nblk(e->edges_upper); if (g > 4096) g = 4096; if (g == 0) g = 1;
+    k_csr_count<<<g, 256, 0, e->stream>>>(d);
+    k_csr_gather_deg<<<nblk(used), 256, 0, e->stream>>>(d, used, e->tmp_a);
+    int r = scan_u32(e, e->tmp_a, e->tmp_b, used, 0, nullptr);
+    if (r) return r;
+    k_csr_set_rows<<<nblk(used), 256, 0, e->stream>>>(d, used, e->tmp_b, e->tmp_c);
+    k_csr_fill<<<g, 256, 0, e->stream>>>(d, e->tmp_c);
+    HIPCHK(hipGetLastError());
+    e->csr_dirty = false;
+    return 0;
+}
+
+// ---- drain: run k_step launches until the device says done ---------------------------------------------
+static int run_steps(ocrgpu_engine *e, bool allow_fire, u64 max_launches, bool timing) {
+    Dev &d = e->d;
+    int r = seal(e); if (r) return r;
+    k_begin<<<1, 1, 0, e->stream>>>(d, allow_fire ? 1u : 0u);
+    const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
+    const u32 grid = 1024;
+    u32 batch = allow_fire ? 8 : 2;
+    u64 launched = 0;
+    if (timing && e->have_events) HIPCHK(hipEventRecord(e->ev0, e->stream));
+    for (;;) {
+        for (u32 k = 0; k < batch; ++k) {
+            if (nanny) k_step<true><<<grid, BLK, 0, e->stream>>>(d); else k_step<false><<<grid, BLK, 0, e->stream>>>(d);
+        }
+        launched += batch;
+        HIPCHK(hipMemcpyAsync(e->pinned_done, &d.ctrl->done, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (*e->pinned_done) break;
+        if (launched >= max_launches) break;
+        if (batch < 64) batch *= 2;
+    }
+    if (timing && e->have_events) {
+        HIPCHK(hipEventRecord(e->ev1, e->stream)); HIPCHK(hipEventSynchronize(e->ev1));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->step_ns_total += (u64)(ms * 1e6);
+    }
+    e->launches_total += launched;
+    k_end<<<1, 1, 0, e->stream>>>(d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int drain_events(ocrgpu_engine *e) {
+    // q_begin and q_tail sit in different cache lines of Ctrl: two 4-byte reads, one sync
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 8, &e->d.ctrl->q_begin, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 9, &e->d.ctrl->q_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->pinned_done[9] <= e->pinned_done[8]) return 0; // nothing queued: registrations only
+    return run_steps(e, false, ~0ull, false);
+}
+
+// ---- GUID provider -----------------------------------------------------------------------------------------
+extern "C" int ocrgpu_guid_reserve(ocrgpu_engine_t *e, u32 kind, u64 n, u64 *guids_out, int where) {
+    ENTER(e);
+    if (!guids_out || kind >= 32) FAIL(OCRGPU_EINVAL, "bad argument");
+    if (e->counter + n >= (1ull << 49)) FAIL(OCRGPU_ENOMEM, "GUID counter overflows 49 bits");
+    if (n == 0) return 0;
+    int r = stage_reserve(e, rup(8 * n)); if (r) return r;
+    u64 *dg; r = stage_out_alloc(e, guids_out, n, where, &dg); if (r) return r;
+    k_guid_reserve<<<nblk(n), 256, 0, e->stream>>>(e->d, kind, n, e->counter, dg);
+    e->counter += n;
+    r = stage_out_copy(e, guids_out, dg, n, where); if (r) return r;
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_guid_put(ocrgpu_engine_t *e, u64 n, const u64 *guids, const u64 *vals, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!guids || !vals) FAIL(OCRGPU_EINVAL, "null array");
+    int r = stage_reserve(e, 2 * rup(8 * n)); if (r) return r;
+    const u64 *dg, *dv;
+    if ((r = stage_in(e, guids, n, where, &dg)) || (r = stage_in(e, vals, n, where, &dv))) return r;
+    k_guid_put<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dg, dv);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int ocrgpu_guid_get(ocrgpu_engine_t *e, u64 n, const u64 *guids, u64 *vals_out, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!guids || !vals_out) FAIL(OCRGPU_EINVAL, "null array");
+    int r = stage_reserve(e, 2 * rup(8 * n)); if (r) return r;
+    const u64 *dg; u64 *dv;
+    if ((r = stage_in(e, guids, n, where, &dg)) || (r = stage_out_alloc(e, vals_out, n, where, &dv))) return r;
+    k_guid_get<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dg, dv);
+    if ((r = stage_out_copy(e, vals_out, dv, n, where))) return r;
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_guid_remove(ocrgpu_engine_t *e, u64 n, const u64 *guids, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!guids) FAIL(OCRGPU_EINVAL, "null array");
+    int r = stage_reserve(e, rup(8 * n)); if (r) return r;
+    const u64 *dg; if ((r = stage_in(e, guids, n, where, &dg))) return r;
+    k_guid_remove<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dg);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- creation --------------------------------------------------------------------------------------------------
+extern "C" int ocrgpu_event_create(ocrgpu_engine_t *e, u64 n, const u32 *kind, const s32 *arg, u64 *guids_out, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!kind || !arg || !guids_out) FAIL(OCRGPU_EINVAL, "null array");
+    if ((u64)e->n_evt + n > e->cfg.max_evt) FAIL(OCRGPU_ENOMEM, "max_evt=%u exhausted", e->cfg.max_evt);
+    int r = stage_reserve(e, 2 * rup(4 * n) + rup(8 * n)); if (r) return r;
+    const u32 *dk; const s32 *da; u64 *dg;
+    if ((r = stage_in(e, kind, n, where, &dk)) || (r = stage_in(e, arg, n, where, &da)) || (r = stage_out_alloc(e, guids_out, n, where, &dg))) return r;
+    k_event_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dk, da, e->n_evt, e->counter, dg);
+    e->n_evt += (u32)n; e->counter += n;
+    if ((r = stage_out_copy(e, guids_out, dg, n, where))) return r;
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_db_create(ocrgpu_engine_t *e, u64 n, const u64 *value, const u64 *tag, u64 *guids_out, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!value || !guids_out) FAIL(OCRGPU_EINVAL, "null array");
+    if ((u64)e->n_db + n > e->cfg.max_db) FAIL(OCRGPU_ENOMEM, "max_db=%u exhausted", e->cfg.max_db);
+    int r = stage_reserve(e, 3 * rup(8 * n)); if (r) return r;
+    const u64 *dv, *dt; u64 *dg;
+    if ((r = stage_in(e, value, n, where, &dv)) || (r = stage_in(e, tag, n, where, &dt)) || (r = stage_out_alloc(e, guids_out, n, where, &dg))) return r;
+    k_db_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dv, dt, e->n_db, e->counter, dg);
+    e->n_db += (u32)n; e->counter += n;
+    if ((r = stage_out_copy(e, guids_out, dg, n, where))) return r;
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_edt_create(ocrgpu_engine_t *e, u64 n, const u32 *depc, const u32 *body, const u64 *param0,
+                                 u64 *guids_out, u64 *outevt_out, u64 *outdb_out, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!depc || !body || !guids_out) FAIL(OCRGPU_EINVAL, "null array");
+    if ((u64)e->n_edt + n > e->cfg.max_edt) FAIL(OCRGPU_ENOMEM, "max_edt=%u exhausted", e->cfg.max_edt);
+    int r = stage_reserve(e, 3 * rup(4 * n) + 4 * rup(8 * n) + 256); if (r) return r;
+    const u32 *dd, *db; const u64 *dp; u64 *dg, *doe, *dod; u32 *dsb, *dtot;
+    if ((r = stage_in(e, depc, n, where, &dd)) || (r = stage_in(e, body, n, where, &db)) || (r = stage_in(e, param0, n, where, &dp)) ||
+        (r = stage_out_alloc(e, guids_out, n, where, &dg)) || (r = stage_out_alloc(e, outevt_out, n, where, &doe)) ||
+        (r = stage_out_alloc(e, outdb_out, n, where, &dod))) return r;
+    dsb = (u32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += rup(4 * n);
+    dtot = (u32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += 256;
+    if ((r = scan_u32(e, dd, dsb, n, (u32)e->n_slots, dtot))) return r;
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 4, dtot, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    u64 add = e->pinned_done[4];
+    if (e->n_slots + add > e->d.max_slots) FAIL(OCRGPU_ENOMEM, "max_slots=%llu exhausted", (unsigned long long)e->d.max_slots);
+    k_edt_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dd, db, dp, dsb, e->n_edt, e->counter, dg, doe, dod);
+    e->n_edt += (u32)n; e->n_slots += add; e->counter += 3 * n;
+    if ((r = stage_out_copy(e, guids_out, dg, n, where)) || (r = stage_out_copy(e, outevt_out, doe, n, where)) ||
+        (r = stage_out_copy(e, outdb_out, dod, n, where))) return r;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_edt_set_scripts(ocrgpu_engine_t *e, u64 n, const u64 *edt, const u32 *begin, const u32 *len,
+                                      u64 n_ops, const ocrgpu_script_op_t *ops, int where) {
+    ENTER(e);
+    if (n == 0 || n_ops == 0) return 0;
+    if (!edt || !begin || !len || !ops) FAIL(OCRGPU_EINVAL, "null array");
+    if (e->n_script + n_ops > (u64)e->cfg.max_edt + 1024) FAIL(OCRGPU_ENOMEM, "script pool (max_edt+1024 ops) exhausted");
+    int r = stage_reserve(e, rup(8 * n) + 2 * rup(4 * n) + rup(sizeof(ocrgpu_script_op_t) * n_ops)); if (r) return r;
+    const u64 *de; const u32 *dbg, *dl; const ocrgpu_script_op_t *dops;
+    if ((r = stage_in(e, edt, n, where, &de)) || (r = stage_in(e, begin, n, where, &dbg)) || (r = stage_in(e, len, n, where, &dl)) ||
+        (r = stage_in(e, ops, n_ops, where, &dops))) return r;
+    k_script_ops<<<nblk(n_ops), 256, 0, e->stream>>>(e->d, n_ops, dops, (u32)e->n_script);
+    k_set_scripts<<<nblk(n), 256, 0, e->stream>>>(e->d, n, de, dbg, dl, (u32)e->n_script);
+    e->n_script += n_ops;
+    HIPCHK(hipGetLastError());
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// ---- dependence API -----------------------------------------------------------------------------------------
+extern "C" int ocrgpu_add_dependence(ocrgpu_engine_t *e, u64 n, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!src || !dst || !slot || !mode) FAIL(OCRGPU_EINVAL, "null array");
+    if (e->edges_upper + n > e->d.max_edges) FAIL(OCRGPU_ENOMEM, "max_edges=%llu exhausted", (unsigned long long)e->d.max_edges);
+    int r = stage_reserve(e, 2 * rup(8 * n) + 2 * rup(4 * n)); if (r) return r;
+    const u64 *ds, *dd; const u32 *dsl, *dm;
+    if ((r = stage_in(e, src, n, where, &ds)) || (r = stage_in(e, dst, n, where, &dd)) || (r = stage_in(e, slot, n, where, &dsl)) ||
+        (r = stage_in(e, mode, n, where, &dm))) return r;
+    // registrations first, then the immediate satisfies this batch produced (see DESIGN.md "batch order")
+    k_add_dep<<<nblk(n), 256, 0, e->stream>>>(e->d, n, ds, dd, dsl, dm);
+    HIPCHK(hipGetLastError());
+    e->edges_upper += n; e->csr_dirty = true;
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream)); // staging buffers are reused by the next call
+    return drain_events(e);
+}
+extern "C" int ocrgpu_event_satisfy_slot(ocrgpu_engine_t *e, u64 n, const u64 *evt, const u64 *db, const u32 *slot, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!evt || !db || !slot) FAIL(OCRGPU_EINVAL, "null array");
+    int r = stage_reserve(e, 2 * rup(8 * n) + rup(4 * n)); if (r) return r;
+    const u64 *de, *dd; const u32 *dsl;
+    if ((r = stage_in(e, evt, n, where, &de)) || (r = stage_in(e, db, n, where, &dd)) || (r = stage_in(e, slot, n, where, &dsl))) return r;
+    k_satisfy<<<nblk(n), 256, 0, e->stream>>>(e->d, n, de, dd, dsl);
+    HIPCHK(hipGetLastError());
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return drain_events(e);
+}
+extern "C" int ocrgpu_event_destroy(ocrgpu_engine_t *e, u64 n, const u64 *evt, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!evt) FAIL(OCRGPU_EINVAL, "null array");
+    int r = stage_reserve(e, rup(8 * n)); if (r) return r;
+    const u64 *de; if ((r = stage_in(e, evt, n, where, &de))) return r;
+    k_evt_destroy<<<nblk(n), 256, 0, e->stream>>>(e->d, n, de);
+    HIPCHK(hipGetLastError());
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// ---- worker loop ----------------------------------------------------------------------------------------------
+static int fetch_stats(ocrgpu_engine *e, ocrgpu_stats_t *out) {
+    Ctrl h;
+    HIPCHK(hipMemcpyAsync(&h, e->d.ctrl, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    memset(out, 0, sizeof *out);
+    out->levels = h.n_levels; out->fired = h.n_fired; out->edt_sat = h.n_edt_sat; out->evt_sat = h.n_evt_sat;
+    out->launches = e->launches_total; out->step_kernel_ns = e->step_ns_total;
+    for (int i = 0; i < 8; ++i) out->err[i] = h.err[i];
+    return 0;
+}
+extern "C" int ocrgpu_resolve(ocrgpu_engine_t *e, u64 max_levels, ocrgpu_stats_t *stats_out) {
+    ENTER(e);
+    u64 max_launches = max_levels ? 4 * max_levels + 64 : ~0ull;
+    int r = run_steps(e, true, max_launches, true);
+    if (r) return r;
+    if (stats_out) { r = fetch_stats(e, stats_out); if (r) return r; e->last = *stats_out; }
+    return 0;
+}
+extern "C" int ocrgpu_get_stats(ocrgpu_engine_t *e, ocrgpu_stats_t *out) { ENTER(e); if (!out) FAIL(OCRGPU_EINVAL, "null"); return fetch_stats(e, out); }
+
+extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
+    ENTER(e);
+    int r = seal(e); if (r) return r;
+    Dev &d = e->d; Snapshot &s = e->snap;
+    if (s.valid) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(s.edt_pending); (void)hipFree(s.evt_mut); (void)hipFree(s.fired); (void)hipFree(s.ctrl); s.valid = false; }
+    u64 n_evt_total = (u64)d.max_evt + e->n_edt;
+    HIPCHK(hipMalloc((void **)&s.edt_pending, 4 * (size_t)e->n_edt + 16));
+    HIPCHK(hipMalloc((void **)&s.evt_mut, sizeof(EvtMut) * (size_t)n_evt_total + 16));
+    HIPCHK(hipMalloc((void **)&s.fired, 4 * (size_t)e->n_edt + 16));
+    HIPCHK(hipMalloc((void **)&s.ctrl, sizeof(Ctrl)));
+    s.valid = true; s.n_edt = e->n_edt;
+    HIPCHK(hipMemcpyAsync(s.edt_pending, d.edt_pending, 4 * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(s.evt_mut, d.evt_mut, sizeof(EvtMut) * (size_t)n_evt_total, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(s.fired, d.fired, 4 * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(s.ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
+    ENTER(e);
+    Dev &d = e->d; Snapshot &s = e->snap;
+    if (!s.valid) FAIL(OCRGPU_EINVAL, "no snapshot taken");
+    if (s.n_edt != e->n_edt) FAIL(OCRGPU_EINVAL, "objects were created after the snapshot");
+    u64 n_evt_total = (u64)d.max_evt + e->n_edt;
+    HIPCHK(hipMemcpyAsync(d.edt_pending, s.edt_pending, 4 * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d.evt_mut, s.evt_mut, sizeof(EvtMut) * (size_t)n_evt_total, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d.fired, s.fired, 4 * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d.ctrl, s.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
+    if (e->cfg.flags & OCRGPU_F_NANNY) HIPCHK(hipMemsetAsync(d.slots, 0, 4 * (size_t)e->n_slots, e->stream));
+    return 0;
+}
+
+// ---- results ---------------------------------------------------------------------------------------------------
+extern "C" int ocrgpu_read_edts(ocrgpu_engine_t *e, u64 first, u64 n, s32 *level_out, u64 *val_out, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (first + n > e->n_edt) FAIL(OCRGPU_EINVAL, "EDT range [%llu,%llu) beyond %u created", (unsigned long long)first, (unsigned long long)(first + n), e->n_edt);
+    int r = stage_reserve(e, 2 * rup(4 * n) + rup(8 * n)); if (r) return r;
+    s32 *dl; u64 *dv;
+    if ((r = stage_out_alloc(e, level_out, n, where, &dl)) || (r = stage_out_alloc(e, val_out, n, where, &dv))) return r;
+    if (!dl) { dl = (s32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += rup(4 * n); }
+    k_fill_i32<<<nblk(n), 256, 0, e->stream>>>(dl, n, -1);
+    k_levels<<<2048, 256, 0, e->stream>>>(e->d, first, n, dl);
+    if (dv) k_read_vals<<<nblk(n), 256, 0, e->stream>>>(e->d, first, n, dl, dv);
+    if ((r = stage_out_copy(e, level_out, dl, n, where)) || (r = stage_out_copy(e, val_out, dv, n, where))) return r;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_read_events(ocrgpu_engine_t *e, int which, u64 first, u64 n, u64 *state_out, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!state_out) FAIL(OCRGPU_EINVAL, "null array");
+    if (which == 0 ? first + n > e->n_evt : first + n > e->n_edt) FAIL(OCRGPU_EINVAL, "event range out of bounds");
+    int r = stage_reserve(e, rup(8 * n)); if (r) return r;
+    u64 *ds; if ((r = stage_out_alloc(e, state_out, n, where, &ds))) return r;
+    k_read_events<<<nblk(n), 256, 0, e->stream>>>(e->d, (u32)(which ? e->d.max_evt + first : first), n, ds);
+    if ((r = stage_out_copy(e, state_out, ds, n, where))) return r;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_read_dbs(ocrgpu_engine_t *e, int which, u64 first, u64 n, u64 *value_out, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!value_out) FAIL(OCRGPU_EINVAL, "null array");
+    if (which == 0 ? first + n > e->n_db : first + n > e->n_edt) FAIL(OCRGPU_EINVAL, "DB range out of bounds");
+    int r = stage_reserve(e, rup(8 * n) + rup(4 * n)); if (r) return r;
+    u64 *dv; if ((r = stage_out_alloc(e, value_out, n, where, &dv))) return r;
+    s32 *dl = nullptr;
+    if (which) {
+        dl = (s32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += rup(4 * n);
+        k_fill_i32<<<nblk(n), 256, 0, e->stream>>>(dl, n, -1);
+        k_levels<<<2048, 256, 0, e->stream>>>(e->d, first, n, dl);
+    }
+    k_read_dbs<<<nblk(n), 256, 0, e->stream>>>(e->d, (u32)(which ? e->d.max_db + first : first), n, dl, (u32)first, dv);
+    if ((r = stage_out_copy(e, value_out, dv, n, where))) return r;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_read_fired(ocrgpu_engine_t *e, u64 *n_fired, u64 *n_levels, u32 *ids_out, u64 *level_start_out, int where) {
+    ENTER(e);
+    Ctrl h;
+    HIPCHK(hipMemcpyAsync(&h, e->d.ctrl, sizeof h, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    u64 nf = h.r_end, nl = h.n_levels > e->d.max_levels ? e->d.max_levels : h.n_levels;
+    if (n_fired) *n_fired = nf;
+    if (n_levels) *n_levels = nl;
+    if (ids_out && nf) HIPCHK(hipMemcpyAsync(ids_out, e->d.fired, 4 * nf, where == OCRGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
+    if (level_start_out) {
+        if (where == OCRGPU_DEVICE) FAIL(OCRGPU_ENOTSUP, "level_start_out is host-only");
+        std::vector<u32> ls(nl + 1);
+        if (nl) HIPCHK(hipMemcpyAsync(ls.data(), e->d.level_start, 4 * (nl + 1), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (u64 i = 0; i <= nl; ++i) level_start_out[i] = nl ? ls[i] : 0;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}

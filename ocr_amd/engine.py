@@ -1,0 +1,359 @@
+"""Host-side mirror of the OCR dependence API over libocrgpu's C-ABI (include/ocrgpu.h).
+
+Names and argument meaning follow the reference's public API (ocr/inc/ocr-edt.h, ocr/inc/ocr-db.h):
+``event_create`` = ocrEventCreateParams, ``edt_create`` = ocrEdtCreate, ``add_dependence`` =
+ocrAddDependence, ``event_satisfy_slot`` = ocrEventSatisfySlot, ``db_create`` = ocrDbCreate -- but every
+call takes arrays (one element per API call the reference would have made).  Errors follow the
+reference's convention (0 = ok, OCR_E* codes): a non-zero C return raises :class:`OcrGpuError`.
+
+There is NO CPU path: if libocrgpu.so is missing or no MI355X is visible this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import opstream as ops
+from .opstream import OpStream, Result
+
+HOST, DEVICE = 0, 1
+F_NANNY, F_TIMING = 1, 2
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libocrgpu.so")
+
+
+class OcrGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libocrgpu error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("max_edt", C.c_uint32), ("max_evt", C.c_uint32), ("max_db", C.c_uint32), ("location", C.c_uint32),
+                ("max_slots", C.c_uint64), ("max_edges", C.c_uint64), ("guid_slots", C.c_uint64),
+                ("max_levels", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("levels", C.c_uint64), ("fired", C.c_uint64), ("edt_sat", C.c_uint64), ("evt_sat", C.c_uint64),
+                ("launches", C.c_uint64), ("step_kernel_ns", C.c_uint64), ("err", C.c_uint64 * 8)]
+
+    def as_dict(self):
+        return dict(levels=self.levels, fired=self.fired, edt_sat=self.edt_sat, evt_sat=self.evt_sat,
+                    launches=self.launches, step_kernel_ns=self.step_kernel_ns, err=list(self.err))
+
+
+SCRIPT_OP_DT = np.dtype([("target", "<u8"), ("payload", "<u8"), ("slot", "<u4"), ("op", "u1"), ("payload_kind", "u1"),
+                         ("pad", "<u2")])
+assert SCRIPT_OP_DT.itemsize == 24
+
+EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error", "ocrgpu_abi_version",
+           "ocrgpu_guid_reserve", "ocrgpu_guid_put", "ocrgpu_guid_get", "ocrgpu_guid_remove",
+           "ocrgpu_event_create", "ocrgpu_db_create", "ocrgpu_edt_create", "ocrgpu_edt_set_scripts",
+           "ocrgpu_set_hash_tag_base", "ocrgpu_add_dependence", "ocrgpu_event_satisfy_slot", "ocrgpu_event_destroy",
+           "ocrgpu_resolve", "ocrgpu_snapshot", "ocrgpu_restore", "ocrgpu_sync", "ocrgpu_read_edts",
+           "ocrgpu_read_events", "ocrgpu_read_dbs", "ocrgpu_read_fired", "ocrgpu_get_stats"]
+
+_lib = None
+
+
+def load_library(path=_LIB_PATH):
+    """dlopen libocrgpu.so (no GPU needed for this) and check every symbol include/ocrgpu.h declares."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise OcrGpuError(-2, f"{path} not built (run `python -m ocr_amd.build`); there is no CPU fallback")
+    lib = C.CDLL(path)
+    for name in EXPORTS:
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = C.c_int
+    lib.ocrgpu_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):  # raw device pointer
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One GPU partition of the dependence engine (one policy-domain location)."""
+
+    def __init__(self, max_edt, max_evt=16, max_db=16, max_slots=None, max_edges=None, device=0, location=0,
+                 flags=0, max_levels=0, guid_slots=0):
+        self.lib = load_library()
+        cfg = Config(max_edt=max_edt, max_evt=max_evt, max_db=max_db, location=location,
+                     max_slots=max_slots if max_slots is not None else 8 * max_edt,
+                     max_edges=max_edges if max_edges is not None else 8 * max_edt, guid_slots=guid_slots,
+                     max_levels=max_levels, flags=flags)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        self._chk(self.lib.ocrgpu_init(C.byref(self.h), device, C.byref(cfg)))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise OcrGpuError(rc, (self.lib.ocrgpu_last_error() or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.ocrgpu_fini(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- GUID provider (ocrGuidProviderFcts_t) ----
+    def guid_reserve(self, kind, n):
+        out = np.empty(n, dtype=np.uint64)
+        self._chk(self.lib.ocrgpu_guid_reserve(self.h, C.c_uint32(kind), C.c_uint64(n), _ptr(out), HOST))
+        return out
+
+    def guid_put(self, guids, vals):
+        guids, vals = np.ascontiguousarray(guids, np.uint64), np.ascontiguousarray(vals, np.uint64)
+        self._chk(self.lib.ocrgpu_guid_put(self.h, C.c_uint64(len(guids)), _ptr(guids), _ptr(vals), HOST))
+
+    def guid_get(self, guids):
+        guids = np.ascontiguousarray(guids, np.uint64)
+        out = np.empty(len(guids), dtype=np.uint64)
+        self._chk(self.lib.ocrgpu_guid_get(self.h, C.c_uint64(len(guids)), _ptr(guids), _ptr(out), HOST))
+        return out
+
+    def guid_remove(self, guids):
+        guids = np.ascontiguousarray(guids, np.uint64)
+        self._chk(self.lib.ocrgpu_guid_remove(self.h, C.c_uint64(len(guids)), _ptr(guids), HOST))
+
+    # ---- objects ----
+    def event_create(self, kind, arg=None):
+        kind = np.ascontiguousarray(kind, np.uint32)
+        arg = np.zeros(len(kind), np.int32) if arg is None else np.ascontiguousarray(arg, np.int32)
+        out = np.empty(len(kind), dtype=np.uint64)
+        self._chk(self.lib.ocrgpu_event_create(self.h, C.c_uint64(len(kind)), _ptr(kind), _ptr(arg), _ptr(out), HOST))
+        return out
+
+    def db_create(self, value, tag=None):
+        value = np.ascontiguousarray(value, np.uint64)
+        tag = None if tag is None else np.ascontiguousarray(tag, np.uint64)
+        out = np.empty(len(value), dtype=np.uint64)
+        self._chk(self.lib.ocrgpu_db_create(self.h, C.c_uint64(len(value)), _ptr(value), _ptr(tag), _ptr(out), HOST))
+        return out
+
+    def edt_create(self, depc, body, param0=None):
+        depc, body = np.ascontiguousarray(depc, np.uint32), np.ascontiguousarray(body, np.uint32)
+        param0 = None if param0 is None else np.ascontiguousarray(param0, np.uint64)
+        n = len(depc)
+        g, oe, od = (np.empty(n, dtype=np.uint64) for _ in range(3))
+        self._chk(self.lib.ocrgpu_edt_create(self.h, C.c_uint64(n), _ptr(depc), _ptr(body), _ptr(param0), _ptr(g),
+                                             _ptr(oe), _ptr(od), HOST))
+        return g, oe, od
+
+    def edt_set_scripts(self, edt, begin, length, script_ops):
+        edt = np.ascontiguousarray(edt, np.uint64)
+        begin, length = np.ascontiguousarray(begin, np.uint32), np.ascontiguousarray(length, np.uint32)
+        script_ops = np.ascontiguousarray(script_ops, SCRIPT_OP_DT)
+        self._chk(self.lib.ocrgpu_edt_set_scripts(self.h, C.c_uint64(len(edt)), _ptr(edt), _ptr(begin), _ptr(length),
+                                                  C.c_uint64(len(script_ops)), _ptr(script_ops), HOST))
+
+    def set_hash_tag_base(self, base):
+        self._chk(self.lib.ocrgpu_set_hash_tag_base(self.h, C.c_uint64(base)))
+
+    # ---- dependences ----
+    def add_dependence(self, src, dst, slot, mode, where=HOST):
+        if where == HOST:
+            src, dst = np.ascontiguousarray(src, np.uint64), np.ascontiguousarray(dst, np.uint64)
+            slot, mode = np.ascontiguousarray(slot, np.uint32), np.ascontiguousarray(mode, np.uint32)
+            n = len(src)
+        else:
+            src, dst, slot, mode, n = src
+        self._chk(self.lib.ocrgpu_add_dependence(self.h, C.c_uint64(n), _ptr(src), _ptr(dst), _ptr(slot), _ptr(mode), where))
+
+    def event_satisfy_slot(self, evt, db=None, slot=None):
+        evt = np.ascontiguousarray(evt, np.uint64)
+        db = np.zeros(len(evt), np.uint64) if db is None else np.ascontiguousarray(db, np.uint64)
+        slot = np.zeros(len(evt), np.uint32) if slot is None else np.ascontiguousarray(slot, np.uint32)
+        self._chk(self.lib.ocrgpu_event_satisfy_slot(self.h, C.c_uint64(len(evt)), _ptr(evt), _ptr(db), _ptr(slot), HOST))
+
+    def event_destroy(self, evt):
+        evt = np.ascontiguousarray(evt, np.uint64)
+        self._chk(self.lib.ocrgpu_event_destroy(self.h, C.c_uint64(len(evt)), _ptr(evt), HOST))
+
+    # ---- worker loop ----
+    def resolve(self, max_levels=0):
+        st = Stats()
+        self._chk(self.lib.ocrgpu_resolve(self.h, C.c_uint64(max_levels), C.byref(st)))
+        return st
+
+    def snapshot(self):
+        self._chk(self.lib.ocrgpu_snapshot(self.h))
+
+    def restore(self):
+        self._chk(self.lib.ocrgpu_restore(self.h))
+
+    def sync(self):
+        self._chk(self.lib.ocrgpu_sync(self.h))
+
+    def stats(self):
+        st = Stats()
+        self._chk(self.lib.ocrgpu_get_stats(self.h, C.byref(st)))
+        return st
+
+    # ---- results ----
+    def read_edts(self, first, n):
+        lv, val = np.empty(n, np.int32), np.empty(n, np.uint64)
+        self._chk(self.lib.ocrgpu_read_edts(self.h, C.c_uint64(first), C.c_uint64(n), _ptr(lv), _ptr(val), HOST))
+        return lv, val
+
+    def read_events(self, which, first, n):
+        out = np.empty(n, np.uint64)
+        self._chk(self.lib.ocrgpu_read_events(self.h, which, C.c_uint64(first), C.c_uint64(n), _ptr(out), HOST))
+        return out
+
+    def read_dbs(self, which, first, n):
+        out = np.empty(n, np.uint64)
+        self._chk(self.lib.ocrgpu_read_dbs(self.h, which, C.c_uint64(first), C.c_uint64(n), _ptr(out), HOST))
+        return out
+
+    def read_fired(self):
+        nf, nl = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.ocrgpu_read_fired(self.h, C.byref(nf), C.byref(nl), None, None, HOST))
+        ids = np.empty(nf.value, np.uint32)
+        ls = np.zeros(nl.value + 1, np.uint64)
+        self._chk(self.lib.ocrgpu_read_fired(self.h, C.byref(nf), C.byref(nl), _ptr(ids), _ptr(ls), HOST))
+        return ids, ls
+
+
+class StreamProgram:
+    """An op stream loaded into an :class:`Engine`: the same role oracle/ocr_replay.c plays for the
+    reference runtime, but every op becomes (part of) one batched C-ABI call."""
+
+    def __init__(self, s: OpStream, device=0, flags=0, engine=None, slack=0):
+        self.s = s
+        n_slots = int(s.edt["depc"].sum())
+        n_adddep = int((s.main["op"] == ops.OP_ADD_DEP).sum())
+        self.eng = engine or Engine(max_edt=max(s.n_edt, 1) + slack, max_evt=max(s.n_evt, 1), max_db=max(s.n_db, 1),
+                                    max_slots=n_slots + 1, max_edges=n_adddep + 1, device=device, flags=flags)
+        self.edt_guid = np.zeros(s.n_edt, np.uint64)
+        self.evt_guid = np.zeros(s.n_evt_total, np.uint64)
+        self.db_guid = np.zeros(s.n_db_total, np.uint64)
+        self.edt_order = []  # stream EDT idx in engine creation order
+        self.evt_order = []
+        self.db_order = []
+        self.eng.set_hash_tag_base(s.n_db)
+        self._built = False
+
+    def _guids(self, refs, depv_ok=False):
+        refs = np.asarray(refs, dtype=np.uint64)
+        cls, idx = ops.ref_cls(refs), ops.ref_idx(refs).astype(np.int64)
+        out = np.zeros(len(refs), np.uint64)
+        s = self.s
+        for c, table, base in ((ops.REF_EDT, self.edt_guid, 0), (ops.REF_EVT, self.evt_guid, 0),
+                               (ops.REF_OUTEVT, self.evt_guid, s.n_evt), (ops.REF_DB, self.db_guid, 0),
+                               (ops.REF_OUTDB, self.db_guid, s.n_db)):
+            m = cls == c
+            if m.any():
+                out[m] = table[idx[m] + base]
+        out[cls == ops.REF_UNINIT] = np.uint64(0xFFFFFFFFFFFFFFFE)
+        return out
+
+    def build(self):
+        """Replay the main ops as batched API calls (consecutive ops of one kind = one call)."""
+        s, eng = self.s, self.eng
+        main = s.main
+        if len(main):
+            cuts = np.nonzero(np.diff(main["op"].astype(np.int16)))[0] + 1
+            bounds = np.r_[0, cuts, len(main)]
+        else:
+            bounds = np.array([0])
+        for b0, b1 in zip(bounds[:-1], bounds[1:]):
+            blk = main[b0:b1]
+            op = int(blk["op"][0])
+            if op == ops.OP_EVT_CREATE:
+                idx = blk["a"].astype(np.int64)
+                self.evt_guid[idx] = eng.event_create(s.evt["kind"][idx], s.evt["arg"][idx])
+                self.evt_order += idx.tolist()
+            elif op == ops.OP_DB_CREATE:
+                idx = blk["a"].astype(np.int64)
+                self.db_guid[idx] = eng.db_create(s.db_init[idx], idx.astype(np.uint64))
+                self.db_order += idx.tolist()
+            elif op == ops.OP_EDT_CREATE:
+                idx = blk["a"].astype(np.int64)
+                g, oe, od = eng.edt_create(s.edt["depc"][idx], s.edt["body"][idx], idx.astype(np.uint64))
+                self.edt_guid[idx], self.evt_guid[s.n_evt + idx], self.db_guid[s.n_db + idx] = g, oe, od
+                self.edt_order += idx.tolist()
+            elif op == ops.OP_ADD_DEP:
+                eng.add_dependence(self._guids(blk["a"]), self._guids(blk["b"]), blk["slot"], blk["mode"].astype(np.uint32))
+            elif op == ops.OP_SATISFY:
+                self._set_scripts()
+                eng.event_satisfy_slot(self._guids(blk["a"]), self._guids(blk["b"]), blk["slot"])
+            elif op == ops.OP_EVT_DESTROY:
+                eng.event_destroy(self._guids(blk["a"]))
+            else:
+                raise ValueError(f"bad op {op}")
+        self._set_scripts()
+        self._built = True
+        return self
+
+    def _set_scripts(self):
+        s = self.s
+        if getattr(self, "_scripts_done", False) or len(s.script) == 0:
+            return
+        has = np.nonzero(s.edt["script_len"] > 0)[0]
+        if np.any(self.edt_guid[has] == 0):
+            return  # some scripted EDT not created yet
+        sc = np.zeros(len(s.script), dtype=SCRIPT_OP_DT)
+        sc["target"] = self._guids(s.script["a"])
+        sc["slot"] = s.script["slot"]
+        sc["op"] = s.script["op"]
+        cls = ops.ref_cls(s.script["b"])
+        pk = np.zeros(len(sc), np.uint8)
+        pay = np.zeros(len(sc), np.uint64)
+        m = (cls == ops.REF_DB)
+        pk[m], pay[m] = 1, self._guids(s.script["b"][m])
+        m = (cls == ops.REF_OUTDB)
+        pk[m] = 2  # by construction scripts only name their own output DB
+        m = (cls == ops.REF_DEPV)
+        pk[m], pay[m] = 3, ops.ref_idx(s.script["b"][m])
+        sc["payload_kind"], sc["payload"] = pk, pay
+        self.eng.edt_set_scripts(self.edt_guid[has], s.edt["script_begin"][has], s.edt["script_len"][has], sc)
+        self._scripts_done = True
+
+    def resolve(self):
+        return self.eng.resolve()
+
+    def result(self) -> Result:
+        s, eng = self.s, self.eng
+        lv, val = eng.read_edts(0, s.n_edt) if s.n_edt else (np.zeros(0, np.int32), np.zeros(0, np.uint64))
+        eo = np.asarray(self.edt_order, dtype=np.int64)
+        level = np.full(s.n_edt, -1, np.int32)
+        v = np.zeros(s.n_edt, np.uint64)
+        level[eo], v[eo] = lv[:len(eo)], val[:len(eo)]
+        evs = np.full(s.n_evt_total, ops.EVS_ABSENT, np.uint64)
+        if s.n_evt:
+            xo = np.asarray(self.evt_order, dtype=np.int64)
+            evs[xo] = eng.read_events(0, 0, len(xo))
+        if s.n_edt:
+            evs[s.n_evt + eo] = eng.read_events(1, 0, len(eo))
+        dbv = np.zeros(s.n_db_total, np.uint64)
+        if s.n_db:
+            do = np.asarray(self.db_order, dtype=np.int64)
+            dbv[do] = eng.read_dbs(0, 0, len(do))
+        if s.n_edt:
+            dbv[s.n_db + eo] = eng.read_dbs(1, 0, len(eo))
+        return Result(level, v, evs, dbv)
+
+
+def run_stream(s: OpStream, device=0, flags=F_NANNY):
+    """Build + resolve + read back. Returns (Result, Stats)."""
+    p = StreamProgram(s, device=device, flags=flags).build()
+    st = p.resolve()
+    r = p.result()
+    p.eng.close()
+    return r, st
