@@ -994,7 +994,7 @@ extern "C" int ocrgpu_edt_create(ocrgpu_engine_t *e, u64 n, const u32 *depc, con
     if ((r = scan_u32(e, dd, dsb, n, (u32)e->n_slots, dtot))) return r;
     HIPCHK(hipMemcpyAsync(e->pinned_done + 4, dtot, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    u64 add = e->pinned_done[4];
+    u64 add = e->pinned_done[4] - (u32)e->n_slots; // the scan was seeded with the slots already in use
     if (e->n_slots + add > e->d.max_slots) FAIL(OCRGPU_ENOMEM, "max_slots=%llu exhausted", (unsigned long long)e->d.max_slots);
     k_edt_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dd, db, dp, dsb, e->n_edt, e->counter, dg, doe, dod);
     e->n_edt += (u32)n; e->n_slots += add; e->counter += 3 * n;
