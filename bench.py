@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- dependence satisfactions/sec of the MI355X engine on BASELINE config 2
+(layered random DAG, 10M EDTs, mean fan-in 4, ONCE output events).
+
+One "step" = one full resolve of the built DAG: restore the dependence state (re-arm), satisfy the
+start event through the C-ABI, run the worker loop until the sink EDT has fired.  The DAG is built
+once, before the timed region, and is resident in HBM.  Prints ONE JSON line (see DESIGN.md
+"Measurement" for what each field means and how roofline.achieved is computed).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n-edt 10000000] [--width 10000]
+                    [--no-cpu-baseline] [--no-parity]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-edt", type=int, default=10_000_000)
+    ap.add_argument("--width", type=int, default=10_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-sample-edts", type=int, default=2_000_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libocrgpu has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from ocr_amd import engine, opstream
+
+    # ---- build: every rank owns one partition = one independent layered DAG (seeded per rank) ----
+    seed = opstream.SEED_BASE + 2 + 1000 * rank
+    s = opstream.layered_dag(args.n_edt, args.width, seed=seed)
+    start_op = s.main[-1:]                      # the final ocrEventSatisfy(start)
+    built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
+    t0 = time.time()
+    prog = engine.StreamProgram(built, device=local, flags=engine.F_TIMING).build()
+    eng = prog.eng
+    eng.snapshot()
+    eng.sync()
+    build_s = time.time() - t0
+    start_guid = prog._guids(start_op["a"])
+
+    def step():
+        eng.restore()
+        eng.event_satisfy_slot(start_guid)
+        return eng.resolve()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        st = step()
+    k0 = eng.stats().step_kernel_ns
+    l0 = eng.stats().launches
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    step_kernel_s = (eng.stats().step_kernel_ns - k0) * 1e-9 / args.steps
+    launches = (eng.stats().launches - l0) / args.steps
+
+    n_sat = s.meta["n_satisfactions"]          # EDT pre-slot + latch pre-slot satisfies per resolve
+    assert st.fired == s.n_edt, (st.fired, s.n_edt)
+    assert sum(st.err) == 0, list(st.err)
+    assert st.edt_sat + s.meta["n_leaves"] == n_sat
+
+    parity = "skipped"
+    if not args.no_parity and rank == 0:
+        from oracle import ref as O            # checker only: the CPU restatement, full size
+        ref = O.run_restatement(s)
+        diff = prog.result().diff(ref)
+        if diff:
+            raise SystemExit(f"PARITY FAILURE vs restatement: {diff}")
+        parity = f"bit-exact vs CPU restatement at full size (digest {ref.digest():016x})"
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = n_sat * world / (dt / args.steps)
+        # algorithmic bytes: 16 B per edge satisfied + 20 B per EDT fired
+        alg_bytes = 16 * n_sat + 20 * s.n_edt
+        out = {
+            "metric": "dependence satisfactions/sec (EDTs fired/sec) at 1/2/4/8 MI355X",
+            "value": value, "unit": "satisfactions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"layered random DAG, {args.n_edt} EDTs in {args.n_edt // args.width} layers of {args.width}, "
+                                   f"depc=1+popcount(6 bits) (mean 4), ONCE output events, HASH bodies, latch+sink; "
+                                   f"one independent partition per GPU",
+                       "n_edt": s.n_edt, "n_satisfactions": n_sat, "levels": int(st.levels),
+                       "edts_fired_per_s": s.n_edt * world / (dt / args.steps), "build_s": round(build_s, 2),
+                       "k_step_launches_per_resolve": launches, "parity": parity},
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / step_kernel_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": alg_bytes / step_kernel_s / 1e9 / 8000.0, "traffic": None,
+                         "kernel": "k_step (all launches of one resolve, HIP events on the engine stream)",
+                         "alg_bytes_per_resolve": alg_bytes, "kernel_s_per_resolve": step_kernel_s},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(args):
+    """The REFERENCE runtime (stock x86 pthread/HC config, PTR guids; oracle/_ref/ocr_replay_perf built from the
+    reference sources) resolving a smaller twin of the same DAG on this box's host cores."""
+    from oracle import ref as O
+    from ocr_amd import opstream
+    n = min(args.cpu_sample_edts, args.n_edt)
+    width = min(args.width, n)
+    n -= n % width
+    twin = opstream.layered_dag(n, width)
+    if O.reference_available("perf"):
+        _, info = O.run_reference(twin, workers=1, guid="PTR", flavour="perf", want_result=False, timeout=900)
+        return {"value": info["sat_per_s"], "unit": "satisfactions/s", "cores": 1, "kind": "reference",
+                "sample": f"layered DAG twin, {n} EDTs in layers of {width} ({info['edges']} satisfactions in "
+                          f"{info['resolve_s']:.2f} s), 1 HC worker, timed first-satisfy..sink"}
+    t0 = time.perf_counter()
+    _, st = O.run_restatement(twin, return_stats=True)
+    dt = time.perf_counter() - t0
+    return {"value": twin.meta["n_satisfactions"] / dt, "unit": "satisfactions/s", "cores": 1, "kind": "port",
+            "sample": f"CPU restatement on a {n}-EDT twin, whole run {dt:.2f} s (includes construction)"}
+
+
+if __name__ == "__main__":
+    main()
