@@ -37,6 +37,8 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_
        ERR_Q_OVERFLOW = 5, ERR_LEVEL_OVERFLOW = 6 };
 #define RF_DST_EDT 1u   // record / waiter destination is an EDT pre-slot
 #define RF_MODE_NULL 2u // dependence mode DB_MODE_NULL: the payload is dropped (hc-task.c:1255)
+#define RF_FIRED 4u     // record only: the event already fired (its satisfy logic ran inline), just fan out
+#define RF_PIECE 8u     // record only: fan out piece `slot` (BIG_ROW edges) of the fired event's row
 #define BODY_F_SCRIPT 0x10000u // internal: EDT has a script
 
 struct EvtStatic { u32 row_begin, deg; };           // CSR row of the event's waiters (rebuilt by seal)
@@ -53,6 +55,7 @@ struct alignas(128) Ctrl {
     u32 r_tail; u32 pad1[31];
     u32 q_tail; u32 pad2[31];
     u32 ticket; u32 log_tail; u32 pad3[30];
+    u32 sub_ticket[8 * 32]; // 8 group counters, one cache line each
     u64 n_edt_sat, n_evt_sat, n_fired, n_levels; u32 err[8]; u32 pad4[16];
 };
 
@@ -71,6 +74,7 @@ struct Dev {
     u32 *fired;                 // fired/ready log, grouped by level
     u32 *level_start;           // level_start[L] = offset in `fired`
     Rec *q;                     // satisfy-record log
+    u64 *blk_stats;             // [MAX_GRID][4] per-workgroup counters (no atomics): edt_sat, evt_sat, fired
     Script *scripts;
     // GUID table
     ulonglong2 *gtab; u64 gmask; u32 gshift;
@@ -137,6 +141,24 @@ __device__ __forceinline__ u32 wave_append(u32 *tail, bool pred) {
     return base + rank_in(m);
 }
 
+// workgroup-aggregated append (BLK = 256 = 4 waves): ballot per wave, LDS for the 4 wave counts, ONE global
+// atomic per workgroup.  `lds` = 4 words.  Must be called by every thread of the workgroup.
+__device__ __forceinline__ u32 block_append(u32 *tail, bool pred, u32 *lds) {
+    u64 m = __ballot(pred);
+    u32 wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[wid] = (u32)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 c0 = lds[0], c1 = lds[1], c2 = lds[2], c3 = lds[3], tot = c0 + c1 + c2 + c3;
+        u32 base = tot ? atomicAdd(tail, tot) : 0u;
+        lds[0] = base; lds[1] = base + c0; lds[2] = base + c0 + c1; lds[3] = base + c0 + c1 + c2;
+    }
+    __syncthreads();
+    u32 r = lds[wid] + rank_in(m);
+    __syncthreads();
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // satisfy primitives
 // ------------------------------------------------------------------------------------------------
@@ -198,6 +220,8 @@ __device__ __forceinline__ bool latch_group(const Dev &d, bool is_latch, u32 x, 
 // the hot kernel
 // ------------------------------------------------------------------------------------------------
 #define BLK 256
+#define MAX_GRID 2048
+#define BIG_ROW 2048u  // waiter rows longer than this are split into pieces fanned out by separate workgroups
 #define FIRE_CHUNK 64   // EDTs per workgroup pass: ~4 edges each -> ~256 edges for the 256 lanes
 
 struct Seg { u32 row, end_off, payload; }; // end_off = inclusive prefix sum of degrees
@@ -206,13 +230,13 @@ struct Seg { u32 row, end_off, payload; }; // end_off = inclusive prefix sum of 
 // concatenated rows (binary search of the LDS prefix sums), so a 10k-waiter row and 63 one-waiter
 // rows cost the same number of passes.
 template <bool NANNY>
-__device__ void fan_out(const Dev &d, Seg *seg, u32 nseg, u32 total, u64 &n_edt_sat, u64 &n_evt_q) {
+__device__ void fan_out(const Dev &d, Seg *seg, u32 nseg, u32 total, u32 *lds4, u64 &n_edt_sat, u64 &n_evt_sat) {
     Ctrl *c = d.ctrl;
     for (u32 base = 0; base < total; base += BLK) {
         u32 t = base + threadIdx.x;
         bool act = t < total;
-        bool ready = false, toq = false;
-        u32 dst = 0, slot = 0, payload = 0, flags = 0;
+        bool ready = false, to_evt = false, is_latch = false;
+        u32 dst = 0, slot = 0, payload = 0, flags = 0, kind = 0;
         if (act) {
             u32 lo = 0, hi = nseg - 1; // first segment with end_off > t
             while (lo < hi) { u32 mid = (lo + hi) >> 1; if (seg[mid].end_off > t) hi = mid; else lo = mid + 1; }
@@ -221,17 +245,39 @@ __device__ void fan_out(const Dev &d, Seg *seg, u32 nseg, u32 total, u64 &n_edt_
             u32 wlo = (u32)w;
             dst = wlo & 0x3FFFFFFFu; flags = wlo >> 30; slot = (u32)(w >> 32); payload = seg[lo].payload;
             if (flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, dst, slot, payload, flags); ++n_edt_sat; }
-            else toq = true;
+            else { to_evt = true; kind = (d.evt_mut[dst].state_kind >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
         }
-        u32 ri = wave_append(&c->r_tail, ready);
+        u32 ri = block_append(&c->r_tail, ready, lds4);
         if (ready) d.fired[ri] = dst;
-        u32 qi = wave_append(&c->q_tail, toq);
-        if (toq) {
-            if (qi < d.q_cap) d.q[qi] = Rec{dst, payload, slot, 0u};
-            else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
-            ++n_evt_q;
+        // event -> event dependences: run the destination's satisfy logic right here (commonSatisfyRegNode
+        // recursing into processMessage, hc-event.c:335-367); only an event that FIRES costs a queue record
+        if (__ballot(to_evt)) {
+            bool fire = latch_group(d, is_latch, dst, slot);
+            if (to_evt && !is_latch) {
+                if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM) fire = evt_satisfy_simple(d, dst, kind, payload);
+                else atomicAdd(&c->err[ERR_DEAD_EVENT], 1u);
+            }
+            bool toq = fire && d.evt_static[dst].deg != 0;
+            u32 qi = wave_append(&c->q_tail, toq);
+            if (toq) {
+                if (qi < d.q_cap) d.q[qi] = Rec{dst, payload, 0u, RF_FIRED};
+                else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
+            }
         }
     }
+}
+
+// A fired event whose row is longer than BIG_ROW is not expanded by one workgroup: queue one RF_PIECE record
+// per BIG_ROW edges; the next EVENTS phase spreads the pieces over the grid.
+__device__ __forceinline__ bool split_big_row(const Dev &d, u32 evt, u32 deg, u32 payload) {
+    if (deg <= BIG_ROW) return false;
+    u32 np = (deg + BIG_ROW - 1) / BIG_ROW;
+    u32 qi = atomicAdd(&d.ctrl->q_tail, np);
+    for (u32 k = 0; k < np; ++k) {
+        if (qi + k < d.q_cap) d.q[qi + k] = Rec{evt, payload, k, RF_FIRED | RF_PIECE};
+        else { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); break; }
+    }
+    return true;
 }
 
 // block-wide inclusive scan of one u32 per thread (BLK = 256 = 4 waves), result in LDS-free registers
@@ -251,38 +297,46 @@ template <bool NANNY>
 __global__ __launch_bounds__(BLK) void k_step(Dev d) {
     __shared__ Seg seg[BLK];
     __shared__ u32 wave_sums[4];
+    __shared__ u32 lds4[4];
+    __shared__ u64 red[12];
     Ctrl *c = d.ctrl;
     if (c->done) return;
     const u32 mode = c->mode, level = c->level;
     const u32 r_begin = c->r_begin, r_end = c->r_end, q_begin = c->q_begin, q_end = c->q_end;
-    u64 n_edt_sat = 0, n_evt_sat = 0, n_fired = 0, n_dummy = 0;
+    u64 n_edt_sat = 0, n_evt_sat = 0, n_fired = 0;
+    // Narrow levels: 64 EDTs per workgroup pass (their ~256 edges keep all 256 lanes busy in the fan-out);
+    // wide levels: 256.  Workgroups beyond the work leave at once and take no part in the hand-over below.
+    const u32 count = (mode == MODE_FIRE) ? r_end - r_begin : q_end - q_begin;
+    const u32 chunk = (mode == MODE_FIRE) ? ((count >= 64u * gridDim.x) ? BLK : FIRE_CHUNK) : BLK;
+    u32 part = (count + chunk - 1) / chunk; if (part > gridDim.x) part = gridDim.x; if (part == 0) part = 1;
+    if (blockIdx.x >= part) return;
 
     if (mode == MODE_FIRE) {
         // ---- taskExecute + taskEpilogue for one level (hc-task.c:1864-2181, 1707-1862) ----
-        for (u32 cb = r_begin + blockIdx.x * FIRE_CHUNK; cb < r_end; cb += gridDim.x * FIRE_CHUNK) {
+        for (u32 cb = r_begin + blockIdx.x * chunk; cb < r_end; cb += gridDim.x * chunk) {
             u32 deg = 0; Seg s = {0, 0, 0};
             u32 i = cb + threadIdx.x;
-            if (threadIdx.x < FIRE_CHUNK && i < r_end) {
-                u32 e = d.fired[i];
+            // Critical path per level: fired[i] -> {edt_static, evt_static} -> waiters -> atomicSub -> append.
+            // The body's own loads (pre-slot words, then the DBs they name) are issued early and consumed
+            // AFTER the fan-out, so they ride under it instead of in front of it.
+            const bool mine = threadIdx.x < chunk && i < r_end;
+            u32 e = 0, body = 0, depc = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr;
+            if (mine) {
+                e = d.fired[i];
                 EdtStatic es = d.edt_static[e];
-                u64 id = d.edt_param0[e];
-                u64 v = ocrops_hash_init(id);
-                const u32 *sl = d.slots + es.slot_base;
-                u32 p0 = 0;
-                for (u32 k = 0; k < es.depc; ++k) {
-                    u32 p = sl[k] & 0x7FFFFFFFu;
-                    if (k == 0) p0 = p;
-                    u64 pv = 0, tagp1 = 0;
-                    if (p) { ulonglong2 b = d.db[p - 1]; pv = b.x; tagp1 = b.y + 1; }
-                    v = ocrops_hash_step(v, k, pv, tagp1);
-                }
-                d.edt_val[e] = v;
+                body = es.body; depc = es.depc; sl = d.slots + es.slot_base;
+                const u32 x = d.max_evt + e;
+                EvtStatic st = EvtStatic{0, 0};
+                if (body & OCRBODY_F_OUTEVT) st = d.evt_static[x];
+                id = d.edt_param0[e];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pw[k] = (u32)k < depc ? sl[k] : 0u;
                 u32 ret = 0;
-                u32 kind = OCRBODY_KIND(es.body);
-                if (kind == OCRBODY_HASH) { ret = d.max_db + e + 1; d.db[ret - 1] = make_ulonglong2(v, d.hash_tag_base + id); }
-                else if (kind == OCRBODY_FWD0) ret = p0;
+                const u32 kind = OCRBODY_KIND(body);
+                if (kind == OCRBODY_HASH) ret = d.max_db + e + 1;
+                else if (kind == OCRBODY_FWD0) ret = pw[0] & 0x7FFFFFFFu;
                 ++n_fired;
-                if (es.body & BODY_F_SCRIPT) { // the body's own ocrEventSatisfySlot / ocrEventDestroy calls
+                if (body & BODY_F_SCRIPT) { // the body's own ocrEventSatisfySlot / ocrEventDestroy calls
                     u32 sb = d.edt_script_begin[e], sn = d.edt_script_len[e];
                     for (u32 k = 0; k < sn; ++k) {
                         Script sc = d.scripts[sb + k];
@@ -299,13 +353,12 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d) {
                         }
                     }
                 }
-                if (es.body & OCRBODY_F_OUTEVT) { // epilogue: satisfy the ONCE output event with the returned guid
-                    u32 x = d.max_evt + e;
+                if (body & OCRBODY_F_OUTEVT) { // epilogue: satisfy the ONCE output event with the returned guid
                     ++n_evt_sat;
-                    if (evt_satisfy_simple(d, x, OCREVT_ONCE, ret)) {
-                        EvtStatic st = d.evt_static[x];
-                        deg = st.deg; s.row = st.row_begin; s.payload = ret;
-                    }
+                    bool ok = true;
+                    if (NANNY) ok = evt_satisfy_simple(d, x, OCREVT_ONCE, ret);
+                    else d.evt_mut[x].state_kind = ST_DESTROYED | (OCREVT_ONCE << 8); // only its own EDT satisfies it
+                    if (ok && !split_big_row(d, x, st.deg, ret)) { deg = st.deg; s.row = st.row_begin; s.payload = ret; }
                 }
             }
             u32 total;
@@ -313,8 +366,24 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d) {
             s.end_off = incl;
             seg[threadIdx.x] = s;
             __syncthreads();
-            if (total) fan_out<NANNY>(d, seg, BLK, total, n_edt_sat, n_dummy);
+            if (total) fan_out<NANNY>(d, seg, BLK, total, lds4, n_edt_sat, n_evt_sat);
             __syncthreads();
+            if (mine) { // the body proper: fold id + every depv[k] payload (8 pre-slots per round of loads)
+                u64 v = ocrops_hash_init(id);
+                for (u32 k0 = 0; k0 < depc; k0 += 8) {
+                    if (k0) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) pw[k] = k0 + k < depc ? sl[k0 + k] : 0u;
+                    }
+                    ulonglong2 b[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { u32 pp = pw[k] & 0x7FFFFFFFu; b[k] = pp ? d.db[pp - 1] : make_ulonglong2(0, ~0ULL); }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (k0 + k < depc) v = ocrops_hash_step(v, k0 + k, b[k].x, b[k].y + 1);
+                }
+                d.edt_val[e] = v;
+                if (OCRBODY_KIND(body) == OCRBODY_HASH) d.db[d.max_db + e] = make_ulonglong2(v, d.hash_tag_base + id);
+            }
         }
     } else {
         // ---- queued satisfies: API calls, chained events, direct EDT pre-slot satisfies ----
@@ -328,42 +397,51 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d) {
             if (act) {
                 r = d.q[i];
                 if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, r.dst, r.slot, r.payload, r.flags); ++n_edt_sat; }
-                else { kind = (d.evt_mut[r.dst].state_kind >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
+                else if (!(r.flags & RF_FIRED)) { kind = (d.evt_mut[r.dst].state_kind >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
             }
-            u32 ri = wave_append(&c->r_tail, ready);
+            u32 ri = block_append(&c->r_tail, ready, lds4);
             if (ready) d.fired[ri] = r.dst;
             bool fire = latch_group(d, is_latch, r.dst, r.slot);
-            if (act && !(r.flags & RF_DST_EDT) && !is_latch) {
+            if (act && (r.flags & RF_FIRED)) fire = true;
+            else if (act && !(r.flags & RF_DST_EDT) && !is_latch) {
                 if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM) fire = evt_satisfy_simple(d, r.dst, kind, r.payload);
                 else atomicAdd(&c->err[(d.evt_mut[r.dst].state_kind & 0xFF) == ST_ABSENT ? ERR_BAD_OP : ERR_DEAD_EVENT], 1u);
             }
-            if (fire) { EvtStatic st = d.evt_static[r.dst]; deg = st.deg; s.row = st.row_begin; s.payload = r.payload; }
+            if (fire) {
+                EvtStatic st = d.evt_static[r.dst];
+                if (r.flags & RF_PIECE) { u32 off = r.slot * BIG_ROW; deg = st.deg - off < BIG_ROW ? st.deg - off : BIG_ROW; s.row = st.row_begin + off; s.payload = r.payload; }
+                else if (!split_big_row(d, r.dst, st.deg, r.payload)) { deg = st.deg; s.row = st.row_begin; s.payload = r.payload; }
+            }
             u32 total;
             u32 incl = block_inclusive_scan(deg, wave_sums, total);
             s.end_off = incl;
             seg[threadIdx.x] = s;
             __syncthreads();
-            if (total) fan_out<NANNY>(d, seg, BLK, total, n_edt_sat, n_dummy);
+            if (total) fan_out<NANNY>(d, seg, BLK, total, lds4, n_edt_sat, n_evt_sat);
             __syncthreads();
         }
     }
 
-    // ---- statistics: one atomic per wave per counter ----
+    // ---- statistics: wave shuffle -> LDS -> this workgroup's own slot (plain +=, no atomics) ----
     for (int o = 32; o > 0; o >>= 1) {
         n_edt_sat += __shfl_down(n_edt_sat, o); n_evt_sat += __shfl_down(n_evt_sat, o); n_fired += __shfl_down(n_fired, o);
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (n_edt_sat) atomicAdd((unsigned long long *)&c->n_edt_sat, (unsigned long long)n_edt_sat);
-        if (n_evt_sat) atomicAdd((unsigned long long *)&c->n_evt_sat, (unsigned long long)n_evt_sat);
-        if (n_fired) atomicAdd((unsigned long long *)&c->n_fired, (unsigned long long)n_fired);
-    }
+    if ((threadIdx.x & 63) == 0) { u32 w = threadIdx.x >> 6; red[w * 3] = n_edt_sat; red[w * 3 + 1] = n_evt_sat; red[w * 3 + 2] = n_fired; }
     // ---- the last workgroup to finish picks the next phase (scheduler "get work", on the device) ----
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        u32 t = atomicAdd(&c->ticket, 1u);
-        if (t == gridDim.x - 1) {
-            c->ticket = 0;
+        u64 a0 = red[0] + red[3] + red[6] + red[9], a1 = red[1] + red[4] + red[7] + red[10], a2 = red[2] + red[5] + red[8] + red[11];
+        if (a0 | a1 | a2) { u64 *bs = d.blk_stats + 4 * blockIdx.x; bs[0] += a0; bs[1] += a1; bs[2] += a2; }
+        // every append of this workgroup is a returned atomic that completed before the barrier above,
+        // so the ticket (device scope, like them) orders after them: no fence needed
+        // two-level hand-over: 8 group counters (own cache lines), then one top counter
+        const u32 g = blockIdx.x & 7u, gsize = (part + 7u - g) >> 3, ngroups = part < 8u ? part : 8u;
+        bool last = false;
+        if (atomicAdd(&c->sub_ticket[g * 32], 1u) == gsize - 1) {
+            c->sub_ticket[g * 32] = 0;
+            if (atomicAdd(&c->ticket, 1u) == ngroups - 1) { c->ticket = 0; last = true; }
+        }
+        if (last) {
             u32 q_tail = atomicAdd(&c->q_tail, 0u), r_tail = atomicAdd(&c->r_tail, 0u);
             if (q_tail > d.q_cap) q_tail = d.q_cap;
             if (q_tail > q_end) { c->mode = MODE_EVENTS; c->q_begin = q_end; c->q_end = q_tail; }
@@ -671,7 +749,7 @@ struct ocrgpu_engine {
     u32 *tmp_a, *tmp_b, *tmp_c; // scan temporaries sized for max(max_edt, n_evt_total)
     u32 *scan_partials; u64 scan_partials_cap;
     Snapshot snap;
-    hipEvent_t ev0, ev1; bool have_events;
+    hipEvent_t ev0, ev1; bool have_events; u32 step_grid;
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
     u32 *pinned_done;
 };
@@ -773,7 +851,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->have_events = false;
-    e->launches_total = 0; e->step_ns_total = 0; memset(&e->last, 0, sizeof e->last);
+    e->launches_total = 0; e->step_ns_total = 0; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
     d.max_edt = cfg->max_edt; d.max_evt = cfg->max_evt; d.max_db = cfg->max_db; d.location = cfg->location;
     d.max_slots = cfg->max_slots ? cfg->max_slots : 1; d.max_edges = cfg->max_edges ? cfg->max_edges : 1;
@@ -803,6 +881,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.fired, 4 * (size_t)cfg->max_edt));
     TRY(dalloc(e, (void **)&d.level_start, 4 * ((size_t)d.max_levels + 2)));
     TRY(dalloc(e, (void **)&d.q, sizeof(Rec) * (size_t)q_cap, false));
+    TRY(dalloc(e, (void **)&d.blk_stats, 8 * 4 * MAX_GRID));
     TRY(dalloc(e, (void **)&d.scripts, sizeof(Script) * ((size_t)cfg->max_edt + 1024)));
     TRY(dalloc(e, (void **)&d.gtab, 16 * (size_t)cap));
     u64 tmpn = n_evt_total > cfg->max_edt ? n_evt_total : cfg->max_edt;
@@ -867,7 +946,7 @@ static int run_steps(ocrgpu_engine *e, bool allow_fire, u64 max_launches, bool t
     int r = seal(e); if (r) return r;
     k_begin<<<1, 1, 0, e->stream>>>(d, allow_fire ? 1u : 0u);
     const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
-    const u32 grid = 1024;
+    const u32 grid = e->step_grid > MAX_GRID ? MAX_GRID : (e->step_grid ? e->step_grid : 256u);
     u32 batch = allow_fire ? 8 : 2;
     u64 launched = 0;
     if (timing && e->have_events) HIPCHK(hipEventRecord(e->ev0, e->stream));
@@ -1068,7 +1147,11 @@ static int fetch_stats(ocrgpu_engine *e, ocrgpu_stats_t *out) {
     HIPCHK(hipMemcpyAsync(&h, e->d.ctrl, sizeof h, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     memset(out, 0, sizeof *out);
-    out->levels = h.n_levels; out->fired = h.n_fired; out->edt_sat = h.n_edt_sat; out->evt_sat = h.n_evt_sat;
+    std::vector<u64> bs(4 * MAX_GRID);
+    HIPCHK(hipMemcpyAsync(bs.data(), e->d.blk_stats, 8 * 4 * MAX_GRID, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    out->levels = h.n_levels;
+    for (u32 b = 0; b < MAX_GRID; ++b) { out->edt_sat += bs[4 * b]; out->evt_sat += bs[4 * b + 1]; out->fired += bs[4 * b + 2]; }
     out->launches = e->launches_total; out->step_kernel_ns = e->step_ns_total;
     for (int i = 0; i < 8; ++i) out->err[i] = h.err[i];
     return 0;
@@ -1111,6 +1194,7 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     HIPCHK(hipMemcpyAsync(d.fired, s.fired, 4 * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.ctrl, s.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
     if (e->cfg.flags & OCRGPU_F_NANNY) HIPCHK(hipMemsetAsync(d.slots, 0, 4 * (size_t)e->n_slots, e->stream));
+    HIPCHK(hipMemsetAsync(d.blk_stats, 0, 8 * 4 * MAX_GRID, e->stream)); // statistics restart with the re-armed DAG
     return 0;
 }
 
