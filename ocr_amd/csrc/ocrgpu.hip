@@ -37,36 +37,58 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_
        ERR_Q_OVERFLOW = 5, ERR_LEVEL_OVERFLOW = 6 };
 #define RF_DST_EDT 1u   // record / waiter destination is an EDT pre-slot
 #define RF_MODE_NULL 2u // dependence mode DB_MODE_NULL: the payload is dropped (hc-task.c:1255)
-#define RF_FIRED 4u     // record only: the event already fired (its satisfy logic ran inline), just fan out
-#define RF_PIECE 8u     // record only: fan out piece `slot` (BIG_ROW edges) of the fired event's row
+#define RF_INLINE 4u    // EDT destination: the pre-slot word lives in the EDT's own 64-B line (depc <= 6)
+#define RF_PREFILLED 8u // EDT destination: the payload was already written at registration (static payload)
+#define RF_FIRED 16u    // record only: the event already fired (its satisfy logic ran inline), just fan out
+#define RF_PIECE 32u    // record only: fan out piece `slot` (BIG_ROW edges) of the fired event's row
+#define INLINE_SLOTS 6u
 #define BODY_F_SCRIPT 0x10000u // internal: EDT has a script
 
-struct EvtStatic { u32 row_begin, deg; };           // CSR row of the event's waiters (rebuilt by seal)
-struct EvtMut { u32 state_kind; s32 val; };         // state | kind<<8 ; LATCH counter / persistent payload
-struct EdtStatic { u32 slot_base, depc, body, pad; };
+// One explicit event = 16 B: CSR row of its waiters (rebuilt by seal) + state | kind<<8 + LATCH counter /
+// persistent payload.
+struct EvtRec { u32 row_begin, deg, state_kind; s32 val; };
+// One EDT = one 64-B line: everything a satisfy or a fire touches for this EDT shares a sector -- the pending
+// counter the atomics hit, the record the firing lane reads, the ONCE output event (event index max_evt+e)
+// and up to 6 pre-slot payload words.  EDTs with depc > 6 keep their slot words in `slots[slot_ovf..]`.
+struct alignas(64) EdtLine {
+    u32 pending, depc, body, out_state;   // out_state: state | kind<<8 of the ONCE output event
+    u64 param0, val;                      // paramv[0]; the body's fold (== value of the output DB)
+    u32 out_row, out_deg;                 // CSR row of the output event's waiters
+    u32 slot[INLINE_SLOTS];               // depc <= 6: the pre-slot words; else slot[0] = base index into `slots`
+};
+static_assert(sizeof(EdtLine) == 64, "EdtLine must be one 64-byte sector");
 struct Rec { u32 dst, payload, slot, flags; };      // one pending satisfy: dst = event idx | EDT idx
 struct Script { u32 target, payload, slot, op_kind; }; // op | payload_kind<<8
 
-struct alignas(128) Ctrl {
-    // written by the last workgroup of a launch, read by every workgroup of the next
+// Phase state of launch K.  EVERY workgroup of launch K derives it from state[(K-1)&1] and the append counters
+// of launch K-1 (all stable once K-1 has ended), so no workgroup waits for another: no ticket, no grid barrier.
+struct alignas(128) State {
     u32 mode, level, r_begin, r_end, q_begin, q_end, done, allow_fire;
-    u32 pad0[24];
-    // atomics (own cache lines)
-    u32 r_tail; u32 pad1[31];
-    u32 q_tail; u32 pad2[31];
-    u32 ticket; u32 log_tail; u32 pad3[30];
-    u32 sub_ticket[8 * 32]; // 8 group counters, one cache line each
-    u64 n_edt_sat, n_evt_sat, n_fired, n_levels; u32 err[8]; u32 pad4[16];
+    u32 r_total, q_total;   // log positions where this launch's appends start
+    u32 n_levels, pad[21];
+};
+struct alignas(128) Cnt { u32 v; u32 pad[31]; };
+struct alignas(128) Ctrl {
+    // between runs ("absolute" view, used by the API kernels and by k_begin / k_end)
+    u32 level, r_end, q_begin, pad0, n_levels, pad1[27];
+    u32 r_tail; u32 pad2[31];   // atomics (own cache lines)
+    u32 q_tail; u32 pad3[31];
+    u32 log_tail; u32 pad4[31];
+    u32 err[8]; u32 pad5[24];
+    // during a run
+    State state[2];
+    Cnt cnt_r[3], cnt_q[3];     // launch K appends through cnt_*[K%3]; launch K+1 reads them; launch K zeroes [(K+1)%3]
+    u32 dummy_val; u32 pad6[31];
 };
 
 struct Dev {
     Ctrl *ctrl;
     // EDTs
-    u32 *edt_pending; EdtStatic *edt_static; u64 *edt_param0; u64 *edt_val; u32 *edt_script_begin, *edt_script_len;
-    u32 *slots;                 // payload word per pre-slot: dbidx+1 (0 = NULL_GUID); bit31 = satisfied (nanny)
-    // events (explicit [0,max_evt) then the output event of EDT e at max_evt+e)
-    EvtStatic *evt_static; EvtMut *evt_mut;
-    u64 *waiters;               // CSR payload: lo = dst | flags<<30 ; hi = absolute slot index | latch slot
+    EdtLine *edt; u32 *edt_script_begin, *edt_script_len;
+    u32 *slots;                 // overflow pre-slot words (depc > 6): dbidx+1 (0 = NULL_GUID); bit31 = satisfied (nanny)
+    // events: explicit [0,max_evt) in `evt`; the output event of EDT e is event max_evt+e and lives in edt[e]
+    EvtRec *evt;
+    u64 *waiters;               // CSR payload: lo = dst ; hi = flags<<28 | (inline slot k | overflow slot index | latch slot)
     u32 *log_src; u64 *log_rec; // registration log the CSR is built from
     // datablocks (explicit [0,max_db) then the output DB of EDT e at max_db+e): {value, tag}
     ulonglong2 *db;
@@ -75,15 +97,22 @@ struct Dev {
     u32 *level_start;           // level_start[L] = offset in `fired`
     Rec *q;                     // satisfy-record log
     u64 *blk_stats;             // [MAX_GRID][4] per-workgroup counters (no atomics): edt_sat, evt_sat, fired
+    u64 *dbg;                   // diagnostic builds only (-DOCRGPU_STAMPS): per-phase time sums of workgroup 0
     Script *scripts;
     // GUID table
     ulonglong2 *gtab; u64 gmask; u32 gshift;
     // sizes
-    u32 max_edt, max_evt, max_db, max_levels, q_cap, location;
+    u32 max_edt, max_evt, max_db, max_levels, q_cap, location, fired_cap;
     u64 max_slots, max_edges, hash_tag_base;
 };
 
 #define TOMB (~0ULL)
+
+// event accessors: explicit events and EDT output events share one index space
+__device__ __forceinline__ u32 *evt_state(const Dev &d, u32 x) { return x < d.max_evt ? &d.evt[x].state_kind : &d.edt[x - d.max_evt].out_state; }
+__device__ __forceinline__ s32 *evt_val(const Dev &d, u32 x) { return x < d.max_evt ? &d.evt[x].val : (s32 *)&d.ctrl->dummy_val; } // output events are ONCE: no value
+__device__ __forceinline__ u32 *evt_deg(const Dev &d, u32 x) { return x < d.max_evt ? &d.evt[x].deg : &d.edt[x - d.max_evt].out_deg; }
+__device__ __forceinline__ u32 *evt_row(const Dev &d, u32 x) { return x < d.max_evt ? &d.evt[x].row_begin : &d.edt[x - d.max_evt].out_row; }
 
 __device__ __forceinline__ u64 mkguid(u32 loc, u32 kind, u64 counter) { return ((u64)loc << 54) | ((u64)kind << 49) | counter; }
 __device__ __forceinline__ u32 ghash(const Dev &d, u64 g) { return (u32)((g * 0x9E3779B97F4A7C15ULL) >> d.gshift); }
@@ -141,51 +170,35 @@ __device__ __forceinline__ u32 wave_append(u32 *tail, bool pred) {
     return base + rank_in(m);
 }
 
-// workgroup-aggregated append (BLK = 256 = 4 waves): ballot per wave, LDS for the 4 wave counts, ONE global
-// atomic per workgroup.  `lds` = 4 words.  Must be called by every thread of the workgroup.
-__device__ __forceinline__ u32 block_append(u32 *tail, bool pred, u32 *lds) {
-    u64 m = __ballot(pred);
-    u32 wid = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) lds[wid] = (u32)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 c0 = lds[0], c1 = lds[1], c2 = lds[2], c3 = lds[3], tot = c0 + c1 + c2 + c3;
-        u32 base = tot ? atomicAdd(tail, tot) : 0u;
-        lds[0] = base; lds[1] = base + c0; lds[2] = base + c0 + c1; lds[3] = base + c0 + c1 + c2;
-    }
-    __syncthreads();
-    u32 r = lds[wid] + rank_in(m);
-    __syncthreads();
-    return r;
-}
-
 // ------------------------------------------------------------------------------------------------
 // satisfy primitives
 // ------------------------------------------------------------------------------------------------
 // satisfyTaskHc (hc-task.c:1216-1266): store the payload word, count the slot, report "all satisfied"
 template <bool NANNY>
-__device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, u32 edt, u32 abs_slot, u32 payload, u32 flags) {
+__device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, u32 edt, u32 slot, u32 payload, u32 flags) {
+    EdtLine *L = &d.edt[edt];
+    u32 *sp = (flags & RF_INLINE) ? &L->slot[slot] : &d.slots[slot];
     u32 word = (flags & RF_MODE_NULL) ? 0u : payload;
     if (NANNY) {
-        u32 old = atomicExch(&d.slots[abs_slot], word | 0x80000000u);
+        u32 old = atomicExch(sp, word | 0x80000000u);
         if (old & 0x80000000u) { atomicAdd(&d.ctrl->err[ERR_DOUBLE_SLOT], 1u); return false; }
-    } else {
-        d.slots[abs_slot] = word;
+    } else if (!(flags & RF_PREFILLED)) {
+        *sp = word;
     }
-    return atomicSub(&d.edt_pending[edt], 1u) == 1u;
+    return atomicSub(&L->pending, 1u) == 1u;
 }
 
 // event.satisfy for ONCE / STICKY / IDEM (hc-event.c:437-465, 569-639).  Returns true when the event
 // fires its waiters with `payload`.  LATCH is handled wave-wide by latch_group().
 __device__ __forceinline__ bool evt_satisfy_simple(const Dev &d, u32 x, u32 kind, u32 payload) {
-    u32 *sk = &d.evt_mut[x].state_kind;
+    u32 *sk = evt_state(d, x);
     if (kind == OCREVT_ONCE) {
         u32 old = atomicExch(sk, ST_DESTROYED | (kind << 8));
         if ((old & 0xFF) != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u); return false; }
         return true;
     }
     u32 old = atomicCAS(sk, ST_LIVE | (kind << 8), ST_SAT | (kind << 8));
-    if ((old & 0xFF) == ST_LIVE) { d.evt_mut[x].val = (s32)payload; return true; }
+    if ((old & 0xFF) == ST_LIVE) { *evt_val(d, x) = (s32)payload; return true; }
     if ((old & 0xFF) == ST_SAT) { if (kind == OCREVT_STICKY) atomicAdd(&d.ctrl->err[ERR_STICKY_RESAT], 1u); }
     else atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
     return false;
@@ -204,11 +217,10 @@ __device__ __forceinline__ bool latch_group(const Dev &d, bool is_latch, u32 x, 
         u64 inc = __ballot(is_latch && x == x0 && slot == OCRLATCH_INCR) & todo;
         s32 delta = (s32)__popcll(inc) - (s32)__popcll(grp & ~inc);
         if ((int)lane_id() == leader) {
-            EvtMut *m = &d.evt_mut[x0];
-            if ((m->state_kind & 0xFF) != ST_LIVE) atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
-            else {
-                s32 old = atomicAdd(&m->val, delta);
-                if (old + delta == 0) { m->state_kind = ST_DESTROYED | (OCREVT_LATCH << 8); fire = true; }
+            s32 old = atomicAdd(evt_val(d, x0), delta); // no state read in front of it: one hop, not two
+            if (old + delta == 0) {
+                u32 was = atomicExch(evt_state(d, x0), ST_DESTROYED | (OCREVT_LATCH << 8));
+                if ((was & 0xFF) == ST_LIVE) fire = true; else atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
             }
         }
         todo &= ~grp;
@@ -221,17 +233,27 @@ __device__ __forceinline__ bool latch_group(const Dev &d, bool is_latch, u32 x, 
 // ------------------------------------------------------------------------------------------------
 #define BLK 256
 #define MAX_GRID 2048
-#define BIG_ROW 2048u  // waiter rows longer than this are split into pieces fanned out by separate workgroups
-#define FIRE_CHUNK 64   // EDTs per workgroup pass: ~4 edges each -> ~256 edges for the 256 lanes
+#define BIG_ROW 2048u        // waiter rows longer than this are split into pieces fanned out by separate workgroups
+#define INVALID 0xFFFFFFFFu  // hole in the ready log (an edge that did not make its EDT ready)
+#define RF_DST_LATCH 2u      // waiter flag when the destination is an event: it is a LATCH (no state read needed)
 
 struct Seg { u32 row, end_off, payload; }; // end_off = inclusive prefix sum of degrees
 
+struct Step { // per-launch constants, identical in every workgroup
+    u32 mode, r_begin, r_end, q_begin, q_end, r_base, q_base; u32 *cnt_r, *cnt_q;
+};
+
 // Fan `nseg` fired events out over the whole workgroup, edge-balanced: lane t takes edge t of the
 // concatenated rows (binary search of the LDS prefix sums), so a 10k-waiter row and 63 one-waiter
-// rows cost the same number of passes.
+// rows cost the same number of passes.  Ready EDTs are NOT compacted here: the workgroup reserves `total`
+// consecutive entries of the ready log up front (one atomic, issued before the waiter loads so it costs no
+// extra round trip) and lane t writes entry t: the EDT it made ready, or INVALID.  Compaction happens on
+// the read side (the FIRE pass skips holes), where it is a ballot instead of a dependent atomic.
 template <bool NANNY>
-__device__ void fan_out(const Dev &d, Seg *seg, u32 nseg, u32 total, u32 *lds4, u64 &n_edt_sat, u64 &n_evt_sat) {
+__device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 total, u32 *lds_base, u64 &n_edt_sat, u64 &n_evt_sat) {
     Ctrl *c = d.ctrl;
+    u32 rbase = 0;
+    if (threadIdx.x == 0) rbase = S.r_base + atomicAdd(S.cnt_r, total);
     for (u32 base = 0; base < total; base += BLK) {
         u32 t = base + threadIdx.x;
         bool act = t < total;
@@ -242,13 +264,17 @@ __device__ void fan_out(const Dev &d, Seg *seg, u32 nseg, u32 total, u32 *lds4, 
             while (lo < hi) { u32 mid = (lo + hi) >> 1; if (seg[mid].end_off > t) hi = mid; else lo = mid + 1; }
             u32 start = lo ? seg[lo - 1].end_off : 0;
             u64 w = d.waiters[seg[lo].row + (t - start)];
-            u32 wlo = (u32)w;
-            dst = wlo & 0x3FFFFFFFu; flags = wlo >> 30; slot = (u32)(w >> 32); payload = seg[lo].payload;
+            u32 whi = (u32)(w >> 32);
+            dst = (u32)w; flags = whi >> 28; slot = whi & 0x0FFFFFFFu; payload = seg[lo].payload;
             if (flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, dst, slot, payload, flags); ++n_edt_sat; }
-            else { to_evt = true; kind = (d.evt_mut[dst].state_kind >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
+            else {
+                to_evt = true; ++n_evt_sat;
+                if (flags & RF_DST_LATCH) { is_latch = true; kind = OCREVT_LATCH; }
+                else kind = (*evt_state(d, dst) >> 8) & 0xFF;
+            }
         }
-        u32 ri = block_append(&c->r_tail, ready, lds4);
-        if (ready) d.fired[ri] = dst;
+        if (base == 0) { if (threadIdx.x == 0) *lds_base = rbase; __syncthreads(); rbase = *lds_base; }
+        if (act) { if (rbase + t < d.fired_cap) d.fired[rbase + t] = ready ? dst : INVALID; else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u); }
         // event -> event dependences: run the destination's satisfy logic right here (commonSatisfyRegNode
         // recursing into processMessage, hc-event.c:335-367); only an event that FIRES costs a queue record
         if (__ballot(to_evt)) {
@@ -257,22 +283,23 @@ __device__ void fan_out(const Dev &d, Seg *seg, u32 nseg, u32 total, u32 *lds4, 
                 if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM) fire = evt_satisfy_simple(d, dst, kind, payload);
                 else atomicAdd(&c->err[ERR_DEAD_EVENT], 1u);
             }
-            bool toq = fire && d.evt_static[dst].deg != 0;
-            u32 qi = wave_append(&c->q_tail, toq);
+            bool toq = fire && *evt_deg(d, dst) != 0;
+            u32 qi = S.q_base + wave_append(S.cnt_q, toq);
             if (toq) {
                 if (qi < d.q_cap) d.q[qi] = Rec{dst, payload, 0u, RF_FIRED};
                 else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
             }
         }
     }
+    __syncthreads(); // lds_base may be rewritten by the next chunk
 }
 
 // A fired event whose row is longer than BIG_ROW is not expanded by one workgroup: queue one RF_PIECE record
 // per BIG_ROW edges; the next EVENTS phase spreads the pieces over the grid.
-__device__ __forceinline__ bool split_big_row(const Dev &d, u32 evt, u32 deg, u32 payload) {
+__device__ __forceinline__ bool split_big_row(const Dev &d, const Step &S, u32 evt, u32 deg, u32 payload) {
     if (deg <= BIG_ROW) return false;
     u32 np = (deg + BIG_ROW - 1) / BIG_ROW;
-    u32 qi = atomicAdd(&d.ctrl->q_tail, np);
+    u32 qi = S.q_base + atomicAdd(S.cnt_q, np);
     for (u32 k = 0; k < np; ++k) {
         if (qi + k < d.q_cap) d.q[qi + k] = Rec{evt, payload, k, RF_FIRED | RF_PIECE};
         else { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); break; }
@@ -280,7 +307,7 @@ __device__ __forceinline__ bool split_big_row(const Dev &d, u32 evt, u32 deg, u3
     return true;
 }
 
-// block-wide inclusive scan of one u32 per thread (BLK = 256 = 4 waves), result in LDS-free registers
+// block-wide inclusive scan of one u32 per thread (BLK = 256 = 4 waves)
 __device__ __forceinline__ u32 block_inclusive_scan(u32 v, u32 *wave_sums, u32 &total) {
     u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (int o = 1; o < 64; o <<= 1) { u32 n = __shfl_up(v, o); if (lane >= (u32)o) v += n; }
@@ -293,48 +320,94 @@ __device__ __forceinline__ u32 block_inclusive_scan(u32 v, u32 *wave_sums, u32 &
     return v + add;
 }
 
+// value + tag of the datablock behind payload word p (p-1 = DB index): explicit DBs live in db[], the output
+// DB of EDT e2 is {edt[e2].val, tag_base + edt[e2].param0} -- one 16-byte read of the producer's line
+__device__ __forceinline__ ulonglong2 db_gather(const Dev &d, u32 p) {
+    if (p == 0) return make_ulonglong2(0, ~0ULL);
+    if (p - 1 < d.max_db) return d.db[p - 1];
+    const ulonglong2 pv = *reinterpret_cast<const ulonglong2 *>(&d.edt[p - 1 - d.max_db].param0);
+    return make_ulonglong2(pv.y, d.hash_tag_base + pv.x);
+}
+
+#ifdef OCRGPU_STAMPS
+#define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { u64 _t = __builtin_amdgcn_s_memrealtime(); d.dbg[k] += _t - _t0; _t0 = _t; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+// One launch = one phase.  K is the launch index (host counter): it selects the state / counter buffers.
 template <bool NANNY>
-__global__ __launch_bounds__(BLK) void k_step(Dev d) {
+__global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
+#ifdef OCRGPU_STAMPS
+    u64 _t0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && K == (u32)d.dbg[15]) d.dbg[16 + 2 * blockIdx.x] = _t0; // per-workgroup entry time of ONE chosen launch
+#endif
     __shared__ Seg seg[BLK];
     __shared__ u32 wave_sums[4];
-    __shared__ u32 lds4[4];
+    __shared__ u32 lds_base;
     __shared__ u64 red[12];
     Ctrl *c = d.ctrl;
-    if (c->done) return;
-    const u32 mode = c->mode, level = c->level;
-    const u32 r_begin = c->r_begin, r_end = c->r_end, q_begin = c->q_begin, q_end = c->q_end;
+    // ---- replicated phase decision (the scheduler's "get work", on the device, without a hand-over) ----
+    const State P = c->state[(K - 1) & 1];
+    if (P.done) { if (blockIdx.x == 0 && threadIdx.x == 0) c->state[K & 1] = P; return; }
+    const u32 r_total = P.r_total + c->cnt_r[(K - 1) % 3].v;
+    u32 q_total = P.q_total + c->cnt_q[(K - 1) % 3].v;
+    if (q_total > d.q_cap) q_total = d.q_cap;
+    State N = P;
+    N.r_total = r_total; N.q_total = q_total;
+    if (q_total > P.q_end) { N.mode = MODE_EVENTS; N.q_begin = P.q_end; N.q_end = q_total; }
+    else if (P.allow_fire && r_total > P.r_end) {
+        N.mode = MODE_FIRE; N.level = P.level + 1; N.r_begin = P.r_end; N.r_end = r_total; N.n_levels = N.level + 1;
+    } else N.done = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        c->state[K & 1] = N;
+        c->cnt_r[(K + 1) % 3].v = 0; c->cnt_q[(K + 1) % 3].v = 0;
+        if (!N.done && N.mode == MODE_FIRE) {
+            if (N.level < d.max_levels) { d.level_start[N.level] = N.r_begin; d.level_start[N.level + 1] = N.r_end; }
+            else atomicAdd(&c->err[ERR_LEVEL_OVERFLOW], 1u);
+        }
+    }
+    if (N.done) return;
+    Step S;
+    S.mode = N.mode; S.r_begin = N.r_begin; S.r_end = N.r_end; S.q_begin = N.q_begin; S.q_end = N.q_end;
+    S.r_base = r_total; S.q_base = q_total; S.cnt_r = &c->cnt_r[K % 3].v; S.cnt_q = &c->cnt_q[K % 3].v;
     u64 n_edt_sat = 0, n_evt_sat = 0, n_fired = 0;
-    // Narrow levels: 64 EDTs per workgroup pass (their ~256 edges keep all 256 lanes busy in the fan-out);
-    // wide levels: 256.  Workgroups beyond the work leave at once and take no part in the hand-over below.
-    const u32 count = (mode == MODE_FIRE) ? r_end - r_begin : q_end - q_begin;
-    const u32 chunk = (mode == MODE_FIRE) ? ((count >= 64u * gridDim.x) ? BLK : FIRE_CHUNK) : BLK;
-    u32 part = (count + chunk - 1) / chunk; if (part > gridDim.x) part = gridDim.x; if (part == 0) part = 1;
-    if (blockIdx.x >= part) return;
+    const u32 count = (S.mode == MODE_FIRE) ? S.r_end - S.r_begin : S.q_end - S.q_begin;
+    u32 part = (count + BLK - 1) / BLK; if (part > gridDim.x) part = gridDim.x;
+    if (blockIdx.x >= part) return; // workgroups beyond the work leave at once
+    STAMP(0);
 
-    if (mode == MODE_FIRE) {
+    if (S.mode == MODE_FIRE) {
         // ---- taskExecute + taskEpilogue for one level (hc-task.c:1864-2181, 1707-1862) ----
-        for (u32 cb = r_begin + blockIdx.x * chunk; cb < r_end; cb += gridDim.x * chunk) {
-            u32 deg = 0; Seg s = {0, 0, 0};
-            u32 i = cb + threadIdx.x;
-            // Critical path per level: fired[i] -> {edt_static, evt_static} -> waiters -> atomicSub -> append.
-            // The body's own loads (pre-slot words, then the DBs they name) are issued early and consumed
-            // AFTER the fan-out, so they ride under it instead of in front of it.
-            const bool mine = threadIdx.x < chunk && i < r_end;
-            u32 e = 0, body = 0, depc = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr;
+        for (u32 cb = S.r_begin + blockIdx.x * BLK; cb < S.r_end; cb += gridDim.x * BLK) {
+            u32 deg = 0; Seg sg = {0, 0, 0};
+            const u32 i = cb + threadIdx.x;
+            // Critical path per level: ready-log entry -> the EDT's 64-B line -> waiter row -> atomicSub -> log store.
+            // The body's gathers (the DBs named by the pre-slot words, which sit in the same line) are issued
+            // BEFORE the fan-out and consumed after it, so they ride under it.
+            u32 e = INVALID;
+            if (i < S.r_end) e = d.fired[i];
+            const bool mine = e != INVALID;
+            u32 body = 0, depc = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr; ulonglong2 gb[8];
             if (mine) {
-                e = d.fired[i];
-                EdtStatic es = d.edt_static[e];
-                body = es.body; depc = es.depc; sl = d.slots + es.slot_base;
+                const EdtLine L = d.edt[e]; // the one 64-B read that carries everything this EDT needs to fire
+                body = L.body; depc = L.depc; id = L.param0;
                 const u32 x = d.max_evt + e;
-                EvtStatic st = EvtStatic{0, 0};
-                if (body & OCRBODY_F_OUTEVT) st = d.evt_static[x];
-                id = d.edt_param0[e];
+                if (depc <= INLINE_SLOTS) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) pw[k] = (u32)k < depc ? sl[k] : 0u;
+                    for (int k = 0; k < 6; ++k) pw[k] = L.slot[k] & 0x7FFFFFFFu;
+                    pw[6] = pw[7] = 0; sl = d.edt[e].slot;
+                } else {
+                    sl = d.slots + L.slot[0];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) pw[k] = (u32)k < depc ? (sl[k] & 0x7FFFFFFFu) : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
                 u32 ret = 0;
                 const u32 kind = OCRBODY_KIND(body);
                 if (kind == OCRBODY_HASH) ret = d.max_db + e + 1;
-                else if (kind == OCRBODY_FWD0) ret = pw[0] & 0x7FFFFFFFu;
+                else if (kind == OCRBODY_FWD0) ret = pw[0];
                 ++n_fired;
                 if (body & BODY_F_SCRIPT) { // the body's own ocrEventSatisfySlot / ocrEventDestroy calls
                     u32 sb = d.edt_script_begin[e], sn = d.edt_script_len[e];
@@ -344,11 +417,11 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d) {
                         if (op == OCRGPU_SOP_SATISFY) {
                             u32 pay = pk == OCRGPU_PAY_GUID ? sc.payload : pk == OCRGPU_PAY_OUTDB ? d.max_db + e + 1
                                     : pk == OCRGPU_PAY_DEPV ? (sl[sc.payload] & 0x7FFFFFFFu) : 0u;
-                            u32 qi = atomicAdd(&c->q_tail, 1u);
+                            u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
                             if (qi < d.q_cap) d.q[qi] = Rec{sc.target, pay, sc.slot, 0u};
                             else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
                         } else { // ocrEventDestroy
-                            u32 old = atomicExch(&d.evt_mut[sc.target].state_kind, (u32)ST_DESTROYED);
+                            u32 old = atomicExch(evt_state(d, sc.target), (u32)ST_DESTROYED);
                             if ((old & 0xFF) != ST_LIVE && (old & 0xFF) != ST_SAT) atomicAdd(&c->err[ERR_DEAD_EVENT], 1u);
                         }
                     }
@@ -357,126 +430,108 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d) {
                     ++n_evt_sat;
                     bool ok = true;
                     if (NANNY) ok = evt_satisfy_simple(d, x, OCREVT_ONCE, ret);
-                    else d.evt_mut[x].state_kind = ST_DESTROYED | (OCREVT_ONCE << 8); // only its own EDT satisfies it
-                    if (ok && !split_big_row(d, x, st.deg, ret)) { deg = st.deg; s.row = st.row_begin; s.payload = ret; }
+                    else d.edt[e].out_state = ST_DESTROYED | (OCREVT_ONCE << 8); // only its own EDT satisfies it
+                    if (ok && !split_big_row(d, S, x, L.out_deg, ret)) { deg = L.out_deg; sg.row = L.out_row; sg.payload = ret; }
                 }
             }
+            STAMP(1);
             u32 total;
             u32 incl = block_inclusive_scan(deg, wave_sums, total);
-            s.end_off = incl;
-            seg[threadIdx.x] = s;
+            sg.end_off = incl;
+            seg[threadIdx.x] = sg;
             __syncthreads();
-            if (total) fan_out<NANNY>(d, seg, BLK, total, lds4, n_edt_sat, n_evt_sat);
-            __syncthreads();
+            STAMP(2);
+            if (total) fan_out<NANNY>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
+            else __syncthreads();
+            STAMP(3);
             if (mine) { // the body proper: fold id + every depv[k] payload (8 pre-slots per round of loads)
                 u64 v = ocrops_hash_init(id);
                 for (u32 k0 = 0; k0 < depc; k0 += 8) {
                     if (k0) {
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) pw[k] = k0 + k < depc ? sl[k0 + k] : 0u;
+                        for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, k0 + k < depc ? (sl[k0 + k] & 0x7FFFFFFFu) : 0u);
                     }
-                    ulonglong2 b[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { u32 pp = pw[k] & 0x7FFFFFFFu; b[k] = pp ? d.db[pp - 1] : make_ulonglong2(0, ~0ULL); }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) if (k0 + k < depc) v = ocrops_hash_step(v, k0 + k, b[k].x, b[k].y + 1);
+                    for (int k = 0; k < 8; ++k) if (k0 + k < depc) v = ocrops_hash_step(v, k0 + k, gb[k].x, gb[k].y + 1);
                 }
-                d.edt_val[e] = v;
-                if (OCRBODY_KIND(body) == OCRBODY_HASH) d.db[d.max_db + e] = make_ulonglong2(v, d.hash_tag_base + id);
+                d.edt[e].val = v; // == the output DB's value (a live DB only for HASH bodies)
             }
         }
     } else {
-        // ---- queued satisfies: API calls, chained events, direct EDT pre-slot satisfies ----
-        for (u32 cb = q_begin + blockIdx.x * BLK; cb < q_end; cb += gridDim.x * BLK) {
-            u32 deg = 0; Seg s = {0, 0, 0};
+        // ---- queued satisfies: API calls, fired chained events, big-row pieces, direct EDT pre-slot satisfies ----
+        for (u32 cb = S.q_begin + blockIdx.x * BLK; cb < S.q_end; cb += gridDim.x * BLK) {
+            u32 deg = 0; Seg sg = {0, 0, 0};
             u32 i = cb + threadIdx.x;
-            bool act = i < q_end;
+            bool act = i < S.q_end;
             Rec r = {0, 0, 0, 0};
             bool ready = false, is_latch = false;
             u32 kind = 0;
             if (act) {
                 r = d.q[i];
                 if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, r.dst, r.slot, r.payload, r.flags); ++n_edt_sat; }
-                else if (!(r.flags & RF_FIRED)) { kind = (d.evt_mut[r.dst].state_kind >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
+                else if (!(r.flags & RF_FIRED)) { kind = (*evt_state(d, r.dst) >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
             }
-            u32 ri = block_append(&c->r_tail, ready, lds4);
+            u32 ri = S.r_base + wave_append(S.cnt_r, ready);
             if (ready) d.fired[ri] = r.dst;
             bool fire = latch_group(d, is_latch, r.dst, r.slot);
             if (act && (r.flags & RF_FIRED)) fire = true;
             else if (act && !(r.flags & RF_DST_EDT) && !is_latch) {
                 if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM) fire = evt_satisfy_simple(d, r.dst, kind, r.payload);
-                else atomicAdd(&c->err[(d.evt_mut[r.dst].state_kind & 0xFF) == ST_ABSENT ? ERR_BAD_OP : ERR_DEAD_EVENT], 1u);
+                else atomicAdd(&c->err[(*evt_state(d, r.dst) & 0xFF) == ST_ABSENT ? ERR_BAD_OP : ERR_DEAD_EVENT], 1u);
             }
             if (fire) {
-                EvtStatic st = d.evt_static[r.dst];
-                if (r.flags & RF_PIECE) { u32 off = r.slot * BIG_ROW; deg = st.deg - off < BIG_ROW ? st.deg - off : BIG_ROW; s.row = st.row_begin + off; s.payload = r.payload; }
-                else if (!split_big_row(d, r.dst, st.deg, r.payload)) { deg = st.deg; s.row = st.row_begin; s.payload = r.payload; }
+                struct { u32 row_begin, deg; } st = {*evt_row(d, r.dst), *evt_deg(d, r.dst)};
+                if (r.flags & RF_PIECE) { u32 off = r.slot * BIG_ROW; deg = st.deg - off < BIG_ROW ? st.deg - off : BIG_ROW; sg.row = st.row_begin + off; sg.payload = r.payload; }
+                else if (!split_big_row(d, S, r.dst, st.deg, r.payload)) { deg = st.deg; sg.row = st.row_begin; sg.payload = r.payload; }
             }
             u32 total;
             u32 incl = block_inclusive_scan(deg, wave_sums, total);
-            s.end_off = incl;
-            seg[threadIdx.x] = s;
+            sg.end_off = incl;
+            seg[threadIdx.x] = sg;
             __syncthreads();
-            if (total) fan_out<NANNY>(d, seg, BLK, total, lds4, n_edt_sat, n_evt_sat);
-            __syncthreads();
+            if (total) fan_out<NANNY>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
+            else __syncthreads();
         }
     }
-
+    STAMP(4);
     // ---- statistics: wave shuffle -> LDS -> this workgroup's own slot (plain +=, no atomics) ----
     for (int o = 32; o > 0; o >>= 1) {
         n_edt_sat += __shfl_down(n_edt_sat, o); n_evt_sat += __shfl_down(n_evt_sat, o); n_fired += __shfl_down(n_fired, o);
     }
     if ((threadIdx.x & 63) == 0) { u32 w = threadIdx.x >> 6; red[w * 3] = n_edt_sat; red[w * 3 + 1] = n_evt_sat; red[w * 3 + 2] = n_fired; }
-    // ---- the last workgroup to finish picks the next phase (scheduler "get work", on the device) ----
     __syncthreads();
     if (threadIdx.x == 0) {
         u64 a0 = red[0] + red[3] + red[6] + red[9], a1 = red[1] + red[4] + red[7] + red[10], a2 = red[2] + red[5] + red[8] + red[11];
         if (a0 | a1 | a2) { u64 *bs = d.blk_stats + 4 * blockIdx.x; bs[0] += a0; bs[1] += a1; bs[2] += a2; }
-        // every append of this workgroup is a returned atomic that completed before the barrier above,
-        // so the ticket (device scope, like them) orders after them: no fence needed
-        // two-level hand-over: 8 group counters (own cache lines), then one top counter
-        const u32 g = blockIdx.x & 7u, gsize = (part + 7u - g) >> 3, ngroups = part < 8u ? part : 8u;
-        bool last = false;
-        if (atomicAdd(&c->sub_ticket[g * 32], 1u) == gsize - 1) {
-            c->sub_ticket[g * 32] = 0;
-            if (atomicAdd(&c->ticket, 1u) == ngroups - 1) { c->ticket = 0; last = true; }
-        }
-        if (last) {
-            u32 q_tail = atomicAdd(&c->q_tail, 0u), r_tail = atomicAdd(&c->r_tail, 0u);
-            if (q_tail > d.q_cap) q_tail = d.q_cap;
-            if (q_tail > q_end) { c->mode = MODE_EVENTS; c->q_begin = q_end; c->q_end = q_tail; }
-            else if (c->allow_fire && r_tail > r_end) {
-                u32 nl = level + 1; // level starts at 0xFFFFFFFF ("main" = level -1)
-                c->mode = MODE_FIRE; c->level = nl; c->q_begin = q_end;
-                c->r_begin = r_end; c->r_end = r_tail;
-                if (nl < d.max_levels) { d.level_start[nl] = r_end; d.level_start[nl + 1] = r_tail; }
-                else atomicAdd(&c->err[ERR_LEVEL_OVERFLOW], 1u);
-                c->n_levels = (u64)nl + 1;
-            } else { c->done = 1; c->q_begin = q_end; }
-        }
     }
+    STAMP(5);
+#ifdef OCRGPU_STAMPS
+    if (threadIdx.x == 0 && K == (u32)d.dbg[15]) d.dbg[17 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
-// Decide the first phase of a drain / resolve (single thread).
-__global__ void k_begin(Dev d, u32 allow_fire) {
+// Start a run at launch index K0: seed state[(K0-1)&1] from the between-runs view (single thread).
+__global__ void k_begin(Dev d, u32 K0, u32 allow_fire) {
     Ctrl *c = d.ctrl;
-    c->allow_fire = allow_fire; c->ticket = 0;
-    u32 q_tail = c->q_tail, r_tail = c->r_tail;
-    if (q_tail > d.q_cap) q_tail = d.q_cap;
-    c->q_end = c->q_begin; // nothing in flight
-    if (q_tail > c->q_begin) { c->mode = MODE_EVENTS; c->q_end = q_tail; c->done = 0; }
-    else if (allow_fire && r_tail > c->r_end) {
-        u32 nl = c->level + 1; // level starts at 0xFFFFFFFF
-        c->mode = MODE_FIRE; c->level = nl; c->r_begin = c->r_end; c->r_end = r_tail; c->done = 0;
-        if (nl < d.max_levels) { d.level_start[nl] = c->r_begin; d.level_start[nl + 1] = r_tail; }
-        else c->err[ERR_LEVEL_OVERFLOW]++;
-        c->n_levels = (u64)nl + 1;
-    } else c->done = 1;
+    State P; memset(&P, 0, sizeof P);
+    P.mode = MODE_EVENTS; P.level = c->level; P.r_begin = P.r_end = c->r_end; P.q_begin = P.q_end = c->q_begin;
+    P.done = 0; P.allow_fire = allow_fire; P.r_total = c->r_tail; P.q_total = c->q_tail > d.q_cap ? d.q_cap : c->q_tail;
+    P.n_levels = c->n_levels;
+    c->state[(K0 - 1) & 1] = P;
+    c->cnt_r[(K0 - 1) % 3].v = 0; c->cnt_q[(K0 - 1) % 3].v = 0;
+    c->cnt_r[K0 % 3].v = 0; c->cnt_q[K0 % 3].v = 0;
 }
-// After a drain: if the record log is fully consumed, rewind it (keeps q_cap small).
-__global__ void k_end(Dev d) {
+// End of a run whose last launch was K: fold the run state back into the between-runs view; if the record
+// log is fully consumed, rewind it (keeps q_cap small).
+__global__ void k_end(Dev d, u32 K) {
     Ctrl *c = d.ctrl;
-    if (c->done && c->q_begin >= c->q_tail) { c->q_begin = c->q_end = 0; c->q_tail = 0; }
+    const State P = c->state[K & 1];
+    c->level = P.level; c->r_end = P.r_end; c->n_levels = P.n_levels;
+    // a finished run made no appends after its totals were folded; an interrupted one (launch budget) did
+    c->r_tail = P.r_total + (P.done ? 0u : c->cnt_r[K % 3].v);
+    u32 qt = P.q_total + (P.done ? 0u : c->cnt_q[K % 3].v);
+    c->q_begin = P.q_end; c->q_tail = qt;
+    if (P.done && P.q_end >= qt) { c->q_begin = 0; c->q_tail = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -486,8 +541,7 @@ __global__ void k_event_create(Dev d, u64 n, const u32 *kind, const s32 *arg, u3
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 k = kind[i], x = first_idx + (u32)i;
-    d.evt_mut[x] = EvtMut{ST_LIVE | (k << 8), k == OCREVT_LATCH ? arg[i] : 0};
-    d.evt_static[x] = EvtStatic{0, 0};
+    d.evt[x] = EvtRec{0, 0, ST_LIVE | (k << 8), k == OCREVT_LATCH ? arg[i] : 0};
     u64 g = mkguid(d.location, evt_kind_to_guid_kind(k), first_counter + i);
     gtab_put(d, g, (u64)x + 1);
     guids_out[i] = g;
@@ -501,26 +555,32 @@ __global__ void k_db_create(Dev d, u64 n, const u64 *value, const u64 *tag, u32 
     gtab_put(d, g, (u64)x + 1);
     guids_out[i] = g;
 }
-// slot_base[] already holds the exclusive scan of depc (+ slots in use)
-__global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, const u64 *param0, const u32 *slot_base,
+// overflow slot words an EDT needs (0 when its pre-slots fit the line)
+__global__ void k_ovf_counts(u64 n, const u32 *depc, u32 *ovf) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) ovf[i] = depc[i] > INLINE_SLOTS ? depc[i] : 0u;
+}
+// slot_ovf[] already holds the exclusive scan of the overflow counts (+ overflow slots in use)
+__global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, const u64 *param0, const u32 *slot_ovf,
                              u32 first_idx, u64 first_counter, u64 *guids_out, u64 *outevt_out, u64 *outdb_out) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 e = first_idx + (u32)i, dc = depc[i], b = body[i] & 0xFFFFu;
-    d.edt_static[e] = EdtStatic{slot_base[i], dc, b, 0};
-    d.edt_pending[e] = dc;
-    d.edt_param0[e] = param0 ? param0[i] : (u64)e;
-    d.edt_val[e] = 0;
+    EdtLine L;
+    L.pending = dc; L.depc = dc; L.body = b;
+    L.param0 = param0 ? param0[i] : (u64)e; L.val = 0;
+    L.out_row = 0; L.out_deg = 0;
+    L.out_state = (b & OCRBODY_F_OUTEVT) ? (ST_LIVE | (OCREVT_ONCE << 8)) : (u32)ST_ABSENT; // ONCE output event (hc-task.c:940-959)
+    for (u32 k = 0; k < INLINE_SLOTS; ++k) L.slot[k] = 0;
+    if (dc > INLINE_SLOTS) L.slot[0] = slot_ovf[i];
+    d.edt[e] = L;
     u64 g = mkguid(d.location, OCRGPU_KIND_EDT, first_counter + 3 * i);
     gtab_put(d, g, (u64)e + 1);
     guids_out[i] = g;
     u64 ge = 0;
-    if (b & OCRBODY_F_OUTEVT) { // ONCE output event (hc-task.c:940-959)
-        u32 x = d.max_evt + e;
-        d.evt_mut[x] = EvtMut{ST_LIVE | (OCREVT_ONCE << 8), 0};
-        d.evt_static[x] = EvtStatic{0, 0};
+    if (b & OCRBODY_F_OUTEVT) {
         ge = mkguid(d.location, OCRGPU_KIND_EVT_ONCE, first_counter + 3 * i + 1);
-        gtab_put(d, ge, (u64)x + 1);
+        gtab_put(d, ge, (u64)(d.max_evt + e) + 1);
     }
     if (outevt_out) outevt_out[i] = ge;
     u64 gd = mkguid(d.location, OCRGPU_KIND_DB, first_counter + 3 * i + 2);
@@ -535,30 +595,32 @@ __device__ __forceinline__ void q_push(const Dev &d, Rec r) {
 }
 __device__ __forceinline__ void bad_op(const Dev &d) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); }
 
-// resolve a destination guid into (idx, is_edt, abs slot)
-__device__ bool resolve_dst(const Dev &d, u64 g, u32 slot, u32 &idx, bool &is_edt, u32 &slot_out) {
+// resolve a destination guid into (idx, flags, encoded slot): inline slot k, overflow slot index, or event slot
+__device__ bool resolve_dst(const Dev &d, u64 g, u32 slot, u32 &idx, u32 &flags, u32 &slot_out) {
     u64 v = gtab_get(d, g);
     if (!v) return false;
     u32 k = OCRGPU_GUID_KIND(g);
     idx = (u32)(v - 1);
     if (k == OCRGPU_KIND_EDT) {
-        EdtStatic es = d.edt_static[idx];
-        if (slot >= es.depc) return false;
-        is_edt = true; slot_out = es.slot_base + slot; return true;
+        u32 depc = d.edt[idx].depc;
+        if (slot >= depc) return false;
+        if (depc <= INLINE_SLOTS) { flags = RF_DST_EDT | RF_INLINE; slot_out = slot; }
+        else { flags = RF_DST_EDT; slot_out = d.edt[idx].slot[0] + slot; if (slot_out >= (1u << 28)) return false; }
+        return true;
     }
     if (!is_event_kind(k)) return false;
-    is_edt = false; slot_out = slot; return true;
+    flags = 0; slot_out = slot; return slot < (1u << 28);
 }
 
 // ocrAddDependence classification (hc-policy.c:2857-3074)
-__global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode) {
+__global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode, u32 nanny) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 s = src[i];
-    u32 didx, dslot; bool d_edt;
-    if (!resolve_dst(d, dst[i], slot[i], didx, d_edt, dslot)) { bad_op(d); return; }
+    u32 didx, dslot, dflag;
+    if (!resolve_dst(d, dst[i], slot[i], didx, dflag, dslot)) { bad_op(d); return; }
+    const bool d_edt = (dflag & RF_DST_EDT) != 0;
     u32 mnull = (d_edt && mode[i] == OCRMODE_NULL) ? RF_MODE_NULL : 0u;
-    u32 dflag = d_edt ? RF_DST_EDT : 0u;
     if (s == OCRGPU_NULL_GUID) { q_push(d, Rec{didx, 0u, dslot, dflag}); return; } // == satisfy(dst, slot, NULL)
     u64 sv = gtab_get(d, s);
     u32 sk = OCRGPU_GUID_KIND(s);
@@ -566,14 +628,28 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
     if (sk == OCRGPU_KIND_DB) { q_push(d, Rec{didx, (u32)sv, dslot, dflag | mnull}); return; } // mode recorded, then satisfy
     if (!is_event_kind(sk)) { bad_op(d); return; }
     u32 x = (u32)(sv - 1);
-    EvtMut m = d.evt_mut[x];
-    u32 st = m.state_kind & 0xFF;
-    if (st == ST_SAT) { q_push(d, Rec{didx, (u32)m.val, dslot, dflag | mnull}); return; } // registerWaiterEventHcPersist :1143-1155
+    u32 st = *evt_state(d, x) & 0xFF;
+    if (st == ST_SAT) { q_push(d, Rec{didx, (u32)*evt_val(d, x), dslot, dflag | mnull}); return; } // registerWaiterEventHcPersist :1143-1155
     if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }    // registerWaiterEventHc :1078-1083
+    // Payload pre-resolution: when what this dependence will deliver is already known -- nothing (DB_MODE_NULL),
+    // or the output DB / NULL_GUID of a built-in HASH / NOP body behind an output event -- write the pre-slot word
+    // now and let the satisfy be a bare counter decrement (no per-edge store on the hot path).
+    u32 pre = 0;
+    if (d_edt && !nanny) {
+        bool known = false; u32 word = 0;
+        if (mnull) known = true;
+        else if (x >= d.max_evt) {
+            u32 se = x - d.max_evt, bk = OCRBODY_KIND(d.edt[se].body);
+            if (bk == OCRBODY_HASH) { known = true; word = d.max_db + se + 1; }
+            else if (bk == OCRBODY_NOP) known = true;
+        }
+        if (known) { pre = RF_PREFILLED; *((dflag & RF_INLINE) ? &d.edt[didx].slot[dslot] : &d.slots[dslot]) = word; }
+    }
     u32 li = atomicAdd(&d.ctrl->log_tail, 1u);
     if (li >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
     d.log_src[li] = x;
-    d.log_rec[li] = ((u64)dslot << 32) | (u64)(didx | ((dflag | mnull) << 30));
+    u32 dlatch = (!d_edt && OCRGPU_GUID_KIND(dst[i]) == OCRGPU_KIND_EVT_LATCH) ? RF_DST_LATCH : 0u;
+    d.log_rec[li] = ((u64)(((dflag | mnull | pre | dlatch) << 28) | dslot) << 32) | (u64)didx;
 }
 
 __global__ void k_satisfy(Dev d, u64 n, const u64 *evt, const u64 *db, const u32 *slot) {
@@ -581,11 +657,11 @@ __global__ void k_satisfy(Dev d, u64 n, const u64 *evt, const u64 *db, const u32
     if (i >= n) return;
     u64 g = evt[i];
     if (g == OCRGPU_NULL_GUID) return; // ocrEventSatisfy(NULL_GUID, ..) is a no-op (ocr-edt.c:171)
-    u32 didx, dslot; bool d_edt;
-    if (!resolve_dst(d, g, slot[i], didx, d_edt, dslot)) { bad_op(d); return; }
+    u32 didx, dslot, dflag;
+    if (!resolve_dst(d, g, slot[i], didx, dflag, dslot)) { bad_op(d); return; }
     u32 pay = 0;
     if (db[i] != OCRGPU_NULL_GUID) { u64 v = gtab_get(d, db[i]); if (!v || OCRGPU_GUID_KIND(db[i]) != OCRGPU_KIND_DB) { bad_op(d); return; } pay = (u32)v; }
-    q_push(d, Rec{didx, pay, dslot, d_edt ? RF_DST_EDT : 0u});
+    q_push(d, Rec{didx, pay, dslot, dflag});
 }
 
 __global__ void k_evt_destroy(Dev d, u64 n, const u64 *evt) {
@@ -593,7 +669,7 @@ __global__ void k_evt_destroy(Dev d, u64 n, const u64 *evt) {
     if (i >= n) return;
     u64 v = gtab_get(d, evt[i]);
     if (!v || !is_event_kind(OCRGPU_GUID_KIND(evt[i]))) { bad_op(d); return; }
-    u32 old = atomicExch(&d.evt_mut[v - 1].state_kind, (u32)ST_DESTROYED);
+    u32 old = atomicExch(evt_state(d, (u32)(v - 1)), (u32)ST_DESTROYED);
     if ((old & 0xFF) != ST_LIVE && (old & 0xFF) != ST_SAT) atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
 }
 
@@ -604,7 +680,7 @@ __global__ void k_set_scripts(Dev d, u64 n, const u64 *edt, const u32 *begin, co
     if (!v || OCRGPU_GUID_KIND(edt[i]) != OCRGPU_KIND_EDT) { bad_op(d); return; }
     u32 e = (u32)(v - 1);
     d.edt_script_begin[e] = script_base + begin[i]; d.edt_script_len[e] = len[i];
-    if (len[i]) d.edt_static[e].body |= BODY_F_SCRIPT;
+    if (len[i]) d.edt[e].body |= BODY_F_SCRIPT;
 }
 __global__ void k_script_ops(Dev d, u64 n, const ocrgpu_script_op_t *ops, u32 script_base) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -620,28 +696,28 @@ __global__ void k_script_ops(Dev d, u64 n, const ocrgpu_script_op_t *ops, u32 sc
 // ---- CSR (re)build from the registration log: count -> scan -> fill --------------------------------
 __global__ void k_csr_clear(Dev d, u32 n_evt_total) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_evt_total) d.evt_static[i].deg = 0;
+    if (i < n_evt_total) *evt_deg(d, i) = 0;
 }
 __global__ void k_csr_count(Dev d) {
     u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         u32 x = d.log_src[i];
-        if ((d.evt_mut[x].state_kind & 0xFF) == ST_LIVE) atomicAdd(&d.evt_static[x].deg, 1u);
+        if ((*evt_state(d, x) & 0xFF) == ST_LIVE) atomicAdd(evt_deg(d, x), 1u);
     }
 }
 __global__ void k_csr_gather_deg(Dev d, u32 n, u32 *deg) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) deg[i] = d.evt_static[i].deg;
+    if (i < n) deg[i] = *evt_deg(d, i);
 }
 __global__ void k_csr_set_rows(Dev d, u32 n, const u32 *row, u32 *cursor) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { d.evt_static[i].row_begin = row[i]; cursor[i] = row[i]; }
+    if (i < n) { *evt_row(d, i) = row[i]; cursor[i] = row[i]; }
 }
 __global__ void k_csr_fill(Dev d, u32 *cursor) {
     u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         u32 x = d.log_src[i];
-        if ((d.evt_mut[x].state_kind & 0xFF) == ST_LIVE) d.waiters[atomicAdd(&cursor[x], 1u)] = d.log_rec[i];
+        if ((*evt_state(d, x) & 0xFF) == ST_LIVE) d.waiters[atomicAdd(&cursor[x], 1u)] = d.log_rec[i];
     }
 }
 
@@ -681,7 +757,7 @@ __global__ void k_guid_get(Dev d, u64 n, const u64 *g, u64 *v) {
     // lazy deletion: an engine-made event guid stops resolving once the event is destroyed
     // (the reference's destructEventHc -> PD_MSG_GUID_DESTROY -> releaseGuid, hc-event.c:185-242)
     if (r && OCRGPU_GUID_LOCATION(g[i]) == d.location && is_event_kind(OCRGPU_GUID_KIND(g[i])) && r <= (u64)d.max_evt + d.max_edt) {
-        u32 st = d.evt_mut[r - 1].state_kind & 0xFF;
+        u32 st = *evt_state(d, (u32)(r - 1)) & 0xFF;
         if (st == ST_DESTROYED || st == ST_ABSENT) r = 0;
     }
     v[i] = r;
@@ -694,11 +770,11 @@ __global__ void k_guid_remove(Dev d, u64 n, const u64 *g) {
 // ---- result readback ------------------------------------------------------------------------------------
 __global__ void k_fill_i32(s32 *p, u64 n, s32 v) { u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 __global__ void k_levels(Dev d, u64 first, u64 n, s32 *level_out) {
-    u32 nf = d.ctrl->r_end, nl = (u32)d.ctrl->n_levels;
+    u32 nf = d.ctrl->r_end, nl = d.ctrl->n_levels;
     if (nl > d.max_levels) nl = d.max_levels;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += gridDim.x * blockDim.x) {
         u32 e = d.fired[i];
-        if (e < first || e >= first + n) continue;
+        if (e == INVALID || e < first || e >= first + n) continue;
         u32 lo = 0, hi = nl; // last level whose start <= i
         while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (d.level_start[mid] <= i) lo = mid; else hi = mid; }
         level_out[e - first] = (s32)lo;
@@ -706,17 +782,17 @@ __global__ void k_levels(Dev d, u64 first, u64 n, s32 *level_out) {
 }
 __global__ void k_read_vals(Dev d, u64 first, u64 n, const s32 *level, u64 *val_out) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) val_out[i] = level[i] >= 0 ? d.edt_val[first + i] : 0; // stale after a restore unless fired
+    if (i < n) val_out[i] = level[i] >= 0 ? d.edt[first + i].val : 0; // stale after a restore unless fired
 }
 __global__ void k_read_events(Dev d, u32 first, u64 n, u64 *out) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    EvtMut m = d.evt_mut[first + i];
+    struct { u32 state_kind; s32 val; } m = {*evt_state(d, first + (u32)i), *evt_val(d, first + (u32)i)};
     u32 st = m.state_kind & 0xFF, kind = (m.state_kind >> 8) & 0xFF;
     u64 r;
     if (st == ST_ABSENT) r = OCREVS(OCREVS_ABSENT, 0);
     else if (st == ST_DESTROYED) r = OCREVS(OCREVS_DESTROYED, 0);
-    else if (st == ST_SAT) r = OCREVS(OCREVS_LIVE_SAT, m.val ? (u32)(d.db[m.val - 1].y + 1) : 0u);
+    else if (st == ST_SAT) r = OCREVS(OCREVS_LIVE_SAT, m.val ? (u32)(db_gather(d, (u32)m.val).y + 1) : 0u);
     else r = OCREVS(OCREVS_LIVE_UNSAT, kind == OCREVT_LATCH ? (u32)m.val : 0u);
     out[i] = r;
 }
@@ -724,8 +800,8 @@ __global__ void k_read_dbs(Dev d, u32 first, u64 n, const s32 *level, u32 first_
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (level) { // output DBs exist once their EDT has fired with a HASH body
-        bool live = level[i] >= 0 && OCRBODY_KIND(d.edt_static[first_edt + i].body) == OCRBODY_HASH;
-        out[i] = live ? d.db[first + i].x : 0;
+        bool live = level[i] >= 0 && OCRBODY_KIND(d.edt[first_edt + i].body) == OCRBODY_HASH;
+        out[i] = live ? d.edt[first_edt + i].val : 0;
     } else out[i] = d.db[first + i].x;
 }
 
@@ -736,7 +812,7 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); return OCRGPU_EHIP; } } while (0)
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
-struct Snapshot { u32 *edt_pending; EvtMut *evt_mut; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt_explicit; bool valid; };
+struct Snapshot { EdtLine *edt; EvtRec *evt; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_fired_entries; bool valid; };
 
 struct ocrgpu_engine {
     int device; hipStream_t stream; ocrgpu_config_t cfg; Dev d;
@@ -749,7 +825,7 @@ struct ocrgpu_engine {
     u32 *tmp_a, *tmp_b, *tmp_c; // scan temporaries sized for max(max_edt, n_evt_total)
     u32 *scan_partials; u64 scan_partials_cap;
     Snapshot snap;
-    hipEvent_t ev0, ev1; bool have_events; u32 step_grid;
+    hipEvent_t ev0, ev1; bool have_events; u32 step_grid; u32 launch_index; u64 fired_cap;
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
     u32 *pinned_done;
 };
@@ -851,7 +927,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->have_events = false;
-    e->launches_total = 0; e->step_ns_total = 0; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
+    e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
     d.max_edt = cfg->max_edt; d.max_evt = cfg->max_evt; d.max_db = cfg->max_db; d.location = cfg->location;
     d.max_slots = cfg->max_slots ? cfg->max_slots : 1; d.max_edges = cfg->max_edges ? cfg->max_edges : 1;
@@ -865,23 +941,23 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     d.gmask = cap - 1; d.gshift = 64 - lg;
 #define TRY(x) do { int _r = (x); if (_r) { ocrgpu_fini(e); return _r; } } while (0)
     TRY(dalloc(e, (void **)&d.ctrl, sizeof(Ctrl)));
-    TRY(dalloc(e, (void **)&d.edt_pending, 4 * (size_t)cfg->max_edt));
-    TRY(dalloc(e, (void **)&d.edt_static, sizeof(EdtStatic) * (size_t)cfg->max_edt));
-    TRY(dalloc(e, (void **)&d.edt_param0, 8 * (size_t)cfg->max_edt));
-    TRY(dalloc(e, (void **)&d.edt_val, 8 * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&d.edt, sizeof(EdtLine) * (size_t)cfg->max_edt));
     TRY(dalloc(e, (void **)&d.edt_script_begin, 4 * (size_t)cfg->max_edt));
     TRY(dalloc(e, (void **)&d.edt_script_len, 4 * (size_t)cfg->max_edt));
     TRY(dalloc(e, (void **)&d.slots, 4 * (size_t)d.max_slots));
-    TRY(dalloc(e, (void **)&d.evt_static, sizeof(EvtStatic) * (size_t)n_evt_total));
-    TRY(dalloc(e, (void **)&d.evt_mut, sizeof(EvtMut) * (size_t)n_evt_total));
+    TRY(dalloc(e, (void **)&d.evt, sizeof(EvtRec) * (size_t)cfg->max_evt));
     TRY(dalloc(e, (void **)&d.waiters, 8 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.log_src, 4 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.log_rec, 8 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.db, 16 * (size_t)n_db_total));
-    TRY(dalloc(e, (void **)&d.fired, 4 * (size_t)cfg->max_edt));
+    u64 fired_cap = (u64)cfg->max_edt + d.max_edges + 4096; if (fired_cap > 0xFFFFFFF0ull) fired_cap = 0xFFFFFFF0ull;
+    e->fired_cap = fired_cap; d.fired_cap = (u32)fired_cap;
+    TRY(dalloc(e, (void **)&d.fired, 4 * (size_t)fired_cap, false));
     TRY(dalloc(e, (void **)&d.level_start, 4 * ((size_t)d.max_levels + 2)));
     TRY(dalloc(e, (void **)&d.q, sizeof(Rec) * (size_t)q_cap, false));
     TRY(dalloc(e, (void **)&d.blk_stats, 8 * 4 * MAX_GRID));
+    TRY(dalloc(e, (void **)&d.dbg, 8 * (16 + 2 * MAX_GRID)));
+    { u64 k = getenv("OCRGPU_STAMP_K") ? (u64)atoll(getenv("OCRGPU_STAMP_K")) : 0; (void)hipMemcpyAsync(&d.dbg[15], &k, 8, hipMemcpyHostToDevice, e->stream); (void)hipStreamSynchronize(e->stream); }
     TRY(dalloc(e, (void **)&d.scripts, sizeof(Script) * ((size_t)cfg->max_edt + 1024)));
     TRY(dalloc(e, (void **)&d.gtab, 16 * (size_t)cap));
     u64 tmpn = n_evt_total > cfg->max_edt ? n_evt_total : cfg->max_edt;
@@ -889,7 +965,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&e->tmp_b, 4 * (size_t)(tmpn + 4)));
     TRY(dalloc(e, (void **)&e->tmp_c, 4 * (size_t)(tmpn + 4)));
     // ctrl.level starts at -1 (main-program satisfies are "level -1")
-    Ctrl h; memset(&h, 0, sizeof h); h.level = 0xFFFFFFFFu; h.done = 1;
+    Ctrl h; memset(&h, 0, sizeof h); h.level = 0xFFFFFFFFu; h.state[0].done = h.state[1].done = 1;
     if (hipMemcpyAsync(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice, e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "ctrl init failed"); }
     if (hipHostMalloc((void **)&e->pinned_done, 64) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
     if (cfg->flags & OCRGPU_F_TIMING) { if (hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess) e->have_events = true; }
@@ -903,10 +979,23 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     if (!e) return 0;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+#ifdef OCRGPU_STAMPS
+    { u64 h[16]; if (e->d.dbg && hipMemcpy(h, e->d.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+        fprintf(stderr, "[stamps, 10ns ticks of workgroup 0 summed over %llu launches] entry %llu | A(loads) %llu | scan %llu | fanout %llu | body %llu | ticket %llu\n",
+                (unsigned long long)e->launches_total, (unsigned long long)h[0], (unsigned long long)h[1], (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)h[4], (unsigned long long)h[5]);
+        std::vector<u64> hb(16 + 2 * MAX_GRID);
+        if (hipMemcpy(hb.data(), e->d.dbg, 8 * hb.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            u64 t0 = ~0ull, e_first = ~0ull, e_last = 0, s_last = 0; int n = 0, last_blk = -1;
+            for (int b = 0; b < MAX_GRID; ++b) { u64 st = hb[16 + 2 * b], en = hb[17 + 2 * b]; if (!st) continue; if (st < t0) t0 = st; if (st > s_last) s_last = st; if (en) { ++n; if (en < e_first) e_first = en; if (en > e_last) { e_last = en; last_blk = b; } } }
+            if (n) fprintf(stderr, "[stamps] launch K=%llu: %d working wgs; last entry +%llu, first end +%llu, last end +%llu (wg %d), wg0 end +%llu  (10ns ticks after the first entry)\n",
+                           (unsigned long long)hb[15], n, (unsigned long long)(s_last - t0), (unsigned long long)(e_first - t0), (unsigned long long)(e_last - t0), last_blk, (unsigned long long)(hb[17] - t0));
+        }
+} }
+#endif
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stage_dev) (void)hipFree(e->stage_dev);
     if (e->scan_partials) (void)hipFree(e->scan_partials);
-    if (e->snap.valid) { (void)hipFree(e->snap.edt_pending); (void)hipFree(e->snap.evt_mut); (void)hipFree(e->snap.fired); (void)hipFree(e->snap.ctrl); }
+    if (e->snap.valid) { (void)hipFree(e->snap.edt); (void)hipFree(e->snap.evt); (void)hipFree(e->snap.fired); (void)hipFree(e->snap.ctrl); }
     if (e->pinned_done) (void)hipHostFree(e->pinned_done);
     if (e->have_events) { (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1); }
     delete e;
@@ -944,18 +1033,20 @@ static int seal(ocrgpu_engine *e) {
 static int run_steps(ocrgpu_engine *e, bool allow_fire, u64 max_launches, bool timing) {
     Dev &d = e->d;
     int r = seal(e); if (r) return r;
-    k_begin<<<1, 1, 0, e->stream>>>(d, allow_fire ? 1u : 0u);
+    if (e->launch_index > 0xFFFF0000u) e->launch_index = 8; // keep K-1 and K%3 arithmetic away from the wrap
+    u32 K = e->launch_index + 1;
+    k_begin<<<1, 1, 0, e->stream>>>(d, K, allow_fire ? 1u : 0u);
     const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
     const u32 grid = e->step_grid > MAX_GRID ? MAX_GRID : (e->step_grid ? e->step_grid : 256u);
     u32 batch = allow_fire ? 8 : 2;
     u64 launched = 0;
     if (timing && e->have_events) HIPCHK(hipEventRecord(e->ev0, e->stream));
     for (;;) {
-        for (u32 k = 0; k < batch; ++k) {
-            if (nanny) k_step<true><<<grid, BLK, 0, e->stream>>>(d); else k_step<false><<<grid, BLK, 0, e->stream>>>(d);
+        for (u32 k = 0; k < batch; ++k, ++K) {
+            if (nanny) k_step<true><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false><<<grid, BLK, 0, e->stream>>>(d, K);
         }
         launched += batch;
-        HIPCHK(hipMemcpyAsync(e->pinned_done, &d.ctrl->done, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(e->pinned_done, &d.ctrl->state[(K - 1) & 1].done, 4, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         if (*e->pinned_done) break;
         if (launched >= max_launches) break;
@@ -967,7 +1058,8 @@ static int run_steps(ocrgpu_engine *e, bool allow_fire, u64 max_launches, bool t
         e->step_ns_total += (u64)(ms * 1e6);
     }
     e->launches_total += launched;
-    k_end<<<1, 1, 0, e->stream>>>(d);
+    e->launch_index = K - 1;
+    k_end<<<1, 1, 0, e->stream>>>(d, K - 1);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1063,14 +1155,16 @@ extern "C" int ocrgpu_edt_create(ocrgpu_engine_t *e, u64 n, const u32 *depc, con
     if (n == 0) return 0;
     if (!depc || !body || !guids_out) FAIL(OCRGPU_EINVAL, "null array");
     if ((u64)e->n_edt + n > e->cfg.max_edt) FAIL(OCRGPU_ENOMEM, "max_edt=%u exhausted", e->cfg.max_edt);
-    int r = stage_reserve(e, 3 * rup(4 * n) + 4 * rup(8 * n) + 256); if (r) return r;
+    int r = stage_reserve(e, 4 * rup(4 * n) + 4 * rup(8 * n) + 256); if (r) return r;
     const u32 *dd, *db; const u64 *dp; u64 *dg, *doe, *dod; u32 *dsb, *dtot;
     if ((r = stage_in(e, depc, n, where, &dd)) || (r = stage_in(e, body, n, where, &db)) || (r = stage_in(e, param0, n, where, &dp)) ||
         (r = stage_out_alloc(e, guids_out, n, where, &dg)) || (r = stage_out_alloc(e, outevt_out, n, where, &doe)) ||
         (r = stage_out_alloc(e, outdb_out, n, where, &dod))) return r;
     dsb = (u32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += rup(4 * n);
     dtot = (u32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += 256;
-    if ((r = scan_u32(e, dd, dsb, n, (u32)e->n_slots, dtot))) return r;
+    u32 *dovf = (u32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += rup(4 * n);
+    k_ovf_counts<<<nblk(n), 256, 0, e->stream>>>(n, dd, dovf);
+    if ((r = scan_u32(e, dovf, dsb, n, (u32)e->n_slots, dtot))) return r;
     HIPCHK(hipMemcpyAsync(e->pinned_done + 4, dtot, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     u64 add = e->pinned_done[4] - (u32)e->n_slots; // the scan was seeded with the slots already in use
@@ -1111,7 +1205,7 @@ extern "C" int ocrgpu_add_dependence(ocrgpu_engine_t *e, u64 n, const u64 *src, 
     if ((r = stage_in(e, src, n, where, &ds)) || (r = stage_in(e, dst, n, where, &dd)) || (r = stage_in(e, slot, n, where, &dsl)) ||
         (r = stage_in(e, mode, n, where, &dm))) return r;
     // registrations first, then the immediate satisfies this batch produced (see DESIGN.md "batch order")
-    k_add_dep<<<nblk(n), 256, 0, e->stream>>>(e->d, n, ds, dd, dsl, dm);
+    k_add_dep<<<nblk(n), 256, 0, e->stream>>>(e->d, n, ds, dd, dsl, dm, (e->cfg.flags & OCRGPU_F_NANNY) ? 1u : 0u);
     HIPCHK(hipGetLastError());
     e->edges_upper += n; e->csr_dirty = true;
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream)); // staging buffers are reused by the next call
@@ -1170,16 +1264,18 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     ENTER(e);
     int r = seal(e); if (r) return r;
     Dev &d = e->d; Snapshot &s = e->snap;
-    if (s.valid) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(s.edt_pending); (void)hipFree(s.evt_mut); (void)hipFree(s.fired); (void)hipFree(s.ctrl); s.valid = false; }
-    u64 n_evt_total = (u64)d.max_evt + e->n_edt;
-    HIPCHK(hipMalloc((void **)&s.edt_pending, 4 * (size_t)e->n_edt + 16));
-    HIPCHK(hipMalloc((void **)&s.evt_mut, sizeof(EvtMut) * (size_t)n_evt_total + 16));
-    HIPCHK(hipMalloc((void **)&s.fired, 4 * (size_t)e->n_edt + 16));
+    if (s.valid) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.fired); (void)hipFree(s.ctrl); s.valid = false; }
+    HIPCHK(hipMalloc((void **)&s.edt, sizeof(EdtLine) * (size_t)e->n_edt + 64));
+    HIPCHK(hipMalloc((void **)&s.evt, sizeof(EvtRec) * (size_t)e->n_evt + 64));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 12, &d.ctrl->r_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    s.n_fired_entries = e->pinned_done[12];
+    HIPCHK(hipMalloc((void **)&s.fired, 4 * (size_t)s.n_fired_entries + 16));
     HIPCHK(hipMalloc((void **)&s.ctrl, sizeof(Ctrl)));
-    s.valid = true; s.n_edt = e->n_edt;
-    HIPCHK(hipMemcpyAsync(s.edt_pending, d.edt_pending, 4 * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(s.evt_mut, d.evt_mut, sizeof(EvtMut) * (size_t)n_evt_total, hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(s.fired, d.fired, 4 * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
+    s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt;
+    HIPCHK(hipMemcpyAsync(s.edt, d.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(s.evt, d.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
+    if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(s.fired, d.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(s.ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
     return 0;
 }
@@ -1187,11 +1283,10 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     ENTER(e);
     Dev &d = e->d; Snapshot &s = e->snap;
     if (!s.valid) FAIL(OCRGPU_EINVAL, "no snapshot taken");
-    if (s.n_edt != e->n_edt) FAIL(OCRGPU_EINVAL, "objects were created after the snapshot");
-    u64 n_evt_total = (u64)d.max_evt + e->n_edt;
-    HIPCHK(hipMemcpyAsync(d.edt_pending, s.edt_pending, 4 * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(d.evt_mut, s.evt_mut, sizeof(EvtMut) * (size_t)n_evt_total, hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(d.fired, s.fired, 4 * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
+    if (s.n_edt != e->n_edt || s.n_evt != e->n_evt) FAIL(OCRGPU_EINVAL, "objects were created after the snapshot");
+    HIPCHK(hipMemcpyAsync(d.edt, s.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d.evt, s.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
+    if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(d.fired, s.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.ctrl, s.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
     if (e->cfg.flags & OCRGPU_F_NANNY) HIPCHK(hipMemsetAsync(d.slots, 0, 4 * (size_t)e->n_slots, e->stream));
     HIPCHK(hipMemsetAsync(d.blk_stats, 0, 8 * 4 * MAX_GRID, e->stream)); // statistics restart with the re-armed DAG
@@ -1246,20 +1341,23 @@ extern "C" int ocrgpu_read_dbs(ocrgpu_engine_t *e, int which, u64 first, u64 n, 
 }
 extern "C" int ocrgpu_read_fired(ocrgpu_engine_t *e, u64 *n_fired, u64 *n_levels, u32 *ids_out, u64 *level_start_out, int where) {
     ENTER(e);
+    if (where == OCRGPU_DEVICE) FAIL(OCRGPU_ENOTSUP, "ocrgpu_read_fired fills host arrays only");
     Ctrl h;
     HIPCHK(hipMemcpyAsync(&h, e->d.ctrl, sizeof h, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    u64 nf = h.r_end, nl = h.n_levels > e->d.max_levels ? e->d.max_levels : h.n_levels;
-    if (n_fired) *n_fired = nf;
-    if (n_levels) *n_levels = nl;
-    if (ids_out && nf) HIPCHK(hipMemcpyAsync(ids_out, e->d.fired, 4 * nf, where == OCRGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream));
-    if (level_start_out) {
-        if (where == OCRGPU_DEVICE) FAIL(OCRGPU_ENOTSUP, "level_start_out is host-only");
-        std::vector<u32> ls(nl + 1);
-        if (nl) HIPCHK(hipMemcpyAsync(ls.data(), e->d.level_start, 4 * (nl + 1), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-        for (u64 i = 0; i <= nl; ++i) level_start_out[i] = nl ? ls[i] : 0;
-    }
+    u64 ne = h.r_end, nl = h.n_levels > e->d.max_levels ? e->d.max_levels : h.n_levels;
+    // the device log has holes (edges that did not ready their EDT): squeeze them out level by level
+    std::vector<u32> raw(ne ? ne : 1), ls(nl + 1);
+    if (ne) HIPCHK(hipMemcpyAsync(raw.data(), e->d.fired, 4 * ne, hipMemcpyDeviceToHost, e->stream));
+    if (nl) HIPCHK(hipMemcpyAsync(ls.data(), e->d.level_start, 4 * (nl + 1), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    u64 w = 0;
+    for (u64 L = 0; L < nl; ++L) {
+        if (level_start_out) level_start_out[L] = w;
+        for (u64 i = ls[L]; i < ls[L + 1]; ++i) if (raw[i] != INVALID) { if (ids_out) ids_out[w] = raw[i]; ++w; }
+    }
+    if (level_start_out) level_start_out[nl] = w;
+    if (n_fired) *n_fired = w;
+    if (n_levels) *n_levels = nl;
     return 0;
 }

@@ -20,7 +20,7 @@ from .opstream import OpStream, Result
 
 HOST, DEVICE = 0, 1
 F_NANNY, F_TIMING = 1, 2
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libocrgpu.so")
+_LIB_PATH = os.environ.get("OCRGPU_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libocrgpu.so")
 
 
 class OcrGpuError(RuntimeError):
