@@ -141,6 +141,25 @@ int ocrgpu_event_destroy(ocrgpu_engine_t *e, uint64_t n, const uint64_t *evt, in
  *      deque.c:190-265, hc-task.c:1707-2181) for EDTs whose bodies are engine built-ins ---------- */
 /* fire ready EDTs level by level until nothing is ready and no satisfy is in flight */
 int ocrgpu_resolve(ocrgpu_engine_t *e, uint64_t max_levels, ocrgpu_stats_t *stats_out);
+/* fire at most `fire_levels` levels (0 = only close pending satisfies), then stop.  OCRGPU_STEP_FORCE_LEVEL:
+ * when nothing is ready here still count one (empty) level, so partitions stepping in lockstep keep the same
+ * level numbering.  *has_ready_out = 1 when EDTs are waiting to fire; *pending_records_out = queued satisfies. */
+#define OCRGPU_STEP_FORCE_LEVEL 1u
+int ocrgpu_step(ocrgpu_engine_t *e, uint32_t fire_levels, uint32_t flags, uint64_t *has_ready_out, uint64_t *pending_records_out);
+
+/* ---- cross-partition satisfies (replace ocrCommPlatformFcts_t.sendMessage/pollMessage for PD_MSG_DEP_SATISFY,
+ *      ocr/src/inc/ocr-comm-platform.h:55-199, mpi-comm-platform.c:1055, hc-dist-policy.c:2208).  The engine fills
+ *      per-destination send buffers with 32-byte records; the caller moves them (RCCL all-to-all over xGMI) and
+ *      hands what it received to ocrgpu_exchange_apply.                                                 ---------- */
+typedef struct { uint64_t guid; uint32_t slot, flags; uint64_t value, tag; } ocrgpu_sendrec_t;   /* 32 B */
+/* send_dev_buf: caller-owned DEVICE buffer of n_locations * records_per_dest records (region r = destination r).
+ * After this call API batches no longer drain by themselves: drive the engine with ocrgpu_step.               */
+int ocrgpu_exchange_config(ocrgpu_engine_t *e, uint32_t n_locations, void *send_dev_buf, uint64_t records_per_dest,
+                           uint64_t max_remote_dsts);
+int ocrgpu_exchange_counts(ocrgpu_engine_t *e, uint32_t *counts_out /* host, [n_locations] */);
+int ocrgpu_exchange_reset(ocrgpu_engine_t *e);
+int ocrgpu_exchange_apply(ocrgpu_engine_t *e, const void *records, uint64_t n, int where);
+
 /* snapshot / restore of all mutable dependence state (benchmark loops re-arm a built DAG) */
 int ocrgpu_snapshot(ocrgpu_engine_t *e);
 int ocrgpu_restore(ocrgpu_engine_t *e);

@@ -59,6 +59,16 @@ struct alignas(64) EdtLine {
 static_assert(sizeof(EdtLine) == 64, "EdtLine must be one 64-byte sector");
 struct Rec { u32 dst, payload, slot, flags; };      // one pending satisfy: dst = event idx | EDT idx
 struct Script { u32 target, payload, slot, op_kind; }; // op | payload_kind<<8
+// A satisfy whose destination lives on another partition (GPU): what crosses xGMI instead of the reference's
+// marshalled ocrPolicyMsg_t (hc-dist-policy.c:2208, mpi-comm-platform.c:1055).  The datablock travels by value
+// (16-byte DBs), the way hc-dist's ProxyDb_t clones it on acquire (hc-dist-policy.c:382-700).
+struct SendRec { u64 guid; u32 slot, flags; u64 value, tag; };  // flags: XF_*
+static_assert(sizeof(SendRec) == 32, "SendRec is 32 bytes");
+#define XF_MODE_NULL 1u
+#define XF_HAS_DB 2u
+#define XF_DESTROY 4u    // ocrEventDestroy of an event owned by another partition
+#define RF_REMOTE 8u     // waiter flag (with bit0 clear): lo = index into rdst[]; bit2 = dst is an EDT, bit1 = MODE_NULL
+struct RemoteDst { u64 guid; u32 slot, flags; };
 
 // Phase state of launch K.  EVERY workgroup of launch K derives it from state[(K-1)&1] and the append counters
 // of launch K-1 (all stable once K-1 has ended), so no workgroup waits for another: no ticket, no grid barrier.
@@ -73,7 +83,7 @@ struct alignas(128) Ctrl {
     u32 level, r_end, q_begin, pad0, n_levels, pad1[27];
     u32 r_tail; u32 pad2[31];   // atomics (own cache lines)
     u32 q_tail; u32 pad3[31];
-    u32 log_tail; u32 pad4[31];
+    u32 log_tail; u32 rdst_tail; u32 pad4[30];
     u32 err[8]; u32 pad5[24];
     // during a run
     State state[2];
@@ -103,6 +113,8 @@ struct Dev {
     ulonglong2 *gtab; u64 gmask; u32 gshift;
     // sizes
     u32 max_edt, max_evt, max_db, max_levels, q_cap, location, fired_cap;
+    // cross-partition satisfies
+    RemoteDst *rdst; u32 rdst_cap; SendRec *send; u32 send_cap, n_loc; u32 *send_cnt; // send_cnt[loc*32]
     u64 max_slots, max_edges, hash_tag_base;
 };
 
@@ -239,6 +251,27 @@ __device__ __forceinline__ bool latch_group(const Dev &d, bool is_latch, u32 x, 
 
 struct Seg { u32 row, end_off, payload; }; // end_off = inclusive prefix sum of degrees
 
+// value + tag of the datablock behind payload word p (p-1 = DB index): explicit DBs live in db[], the output
+// DB of EDT e2 is {edt[e2].val, tag_base + edt[e2].param0} -- one 16-byte read of the producer's line
+__device__ __forceinline__ ulonglong2 db_gather(const Dev &d, u32 p) {
+    if (p == 0) return make_ulonglong2(0, ~0ULL);
+    if (p - 1 < d.max_db) return d.db[p - 1];
+    const ulonglong2 pv = *reinterpret_cast<const ulonglong2 *>(&d.edt[p - 1 - d.max_db].param0);
+    return make_ulonglong2(pv.y, d.hash_tag_base + pv.x);
+}
+
+// queue a satisfy for another partition: per-destination send buffer, DB shipped by value
+__device__ __forceinline__ void emit_remote(const Dev &d, u64 guid, u32 slot, u32 xflags, u32 payload) {
+    u32 loc = OCRGPU_GUID_LOCATION(guid);
+    if (d.send == nullptr || loc >= d.n_loc) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
+    ulonglong2 b = make_ulonglong2(0, 0);
+    if (payload && !(xflags & XF_MODE_NULL)) { b = db_gather(d, payload); xflags |= XF_HAS_DB; }
+    u32 pos = atomicAdd(&d.send_cnt[loc * 32], 1u);
+    if (pos >= d.send_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+    d.send[(size_t)loc * d.send_cap + pos] = SendRec{guid, slot, xflags, b.x, b.y};
+}
+
+
 struct Step { // per-launch constants, identical in every workgroup
     u32 mode, r_begin, r_end, q_begin, q_end, r_base, q_base; u32 *cnt_r, *cnt_q;
 };
@@ -267,6 +300,7 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
             u32 whi = (u32)(w >> 32);
             dst = (u32)w; flags = whi >> 28; slot = whi & 0x0FFFFFFFu; payload = seg[lo].payload;
             if (flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, dst, slot, payload, flags); ++n_edt_sat; }
+            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote(d, rd.guid, rd.slot, rd.flags, payload); }
             else {
                 to_evt = true; ++n_evt_sat;
                 if (flags & RF_DST_LATCH) { is_latch = true; kind = OCREVT_LATCH; }
@@ -320,13 +354,18 @@ __device__ __forceinline__ u32 block_inclusive_scan(u32 v, u32 *wave_sums, u32 &
     return v + add;
 }
 
-// value + tag of the datablock behind payload word p (p-1 = DB index): explicit DBs live in db[], the output
-// DB of EDT e2 is {edt[e2].val, tag_base + edt[e2].param0} -- one 16-byte read of the producer's line
-__device__ __forceinline__ ulonglong2 db_gather(const Dev &d, u32 p) {
-    if (p == 0) return make_ulonglong2(0, ~0ULL);
-    if (p - 1 < d.max_db) return d.db[p - 1];
-    const ulonglong2 pv = *reinterpret_cast<const ulonglong2 *>(&d.edt[p - 1 - d.max_db].param0);
-    return make_ulonglong2(pv.y, d.hash_tag_base + pv.x);
+// the body proper: fold id + every depv[k] payload (8 pre-slots per round of loads; gb = the first round, already loaded)
+__device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, const u32 *sl, ulonglong2 (&gb)[8]) {
+    u64 v = ocrops_hash_init(id);
+    for (u32 k0 = 0; k0 < depc; k0 += 8) {
+        if (k0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, k0 + k < depc ? (sl[k0 + k] & 0x7FFFFFFFu) : 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k0 + k < depc) v = ocrops_hash_step(v, k0 + k, gb[k].x, gb[k].y + 1);
+    }
+    d.edt[e].val = v; // == the output DB's value (a live DB only for HASH bodies)
 }
 
 #ifdef OCRGPU_STAMPS
@@ -357,6 +396,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     N.r_total = r_total; N.q_total = q_total;
     if (q_total > P.q_end) { N.mode = MODE_EVENTS; N.q_begin = P.q_end; N.q_end = q_total; }
     else if (P.allow_fire && r_total > P.r_end) {
+        if (P.allow_fire != 0xFFFFFFFFu) N.allow_fire = P.allow_fire - 1; // FIRE budget (distributed stepping: 1 level)
         N.mode = MODE_FIRE; N.level = P.level + 1; N.r_begin = P.r_end; N.r_end = r_total; N.n_levels = N.level + 1;
     } else N.done = 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -377,6 +417,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     if (blockIdx.x >= part) return; // workgroups beyond the work leave at once
     STAMP(0);
 
+    const bool body_first = d.n_loc > 1;
     if (S.mode == MODE_FIRE) {
         // ---- taskExecute + taskEpilogue for one level (hc-task.c:1864-2181, 1707-1862) ----
         for (u32 cb = S.r_begin + blockIdx.x * BLK; cb < S.r_end; cb += gridDim.x * BLK) {
@@ -409,17 +450,25 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                 if (kind == OCRBODY_HASH) ret = d.max_db + e + 1;
                 else if (kind == OCRBODY_FWD0) ret = pw[0];
                 ++n_fired;
+                // With other partitions around, a satisfy may carry this EDT's output DB away by value in this very
+                // launch, so the body runs first; on a single partition it runs after the fan-out (off the critical path).
+                if (body_first) run_body(d, e, id, depc, sl, gb);
                 if (body & BODY_F_SCRIPT) { // the body's own ocrEventSatisfySlot / ocrEventDestroy calls
                     u32 sb = d.edt_script_begin[e], sn = d.edt_script_len[e];
                     for (u32 k = 0; k < sn; ++k) {
                         Script sc = d.scripts[sb + k];
-                        u32 op = sc.op_kind & 0xFF, pk = sc.op_kind >> 8;
+                        u32 op = sc.op_kind & 0xFF, pk = (sc.op_kind >> 8) & 0xFF;
                         if (op == OCRGPU_SOP_SATISFY) {
                             u32 pay = pk == OCRGPU_PAY_GUID ? sc.payload : pk == OCRGPU_PAY_OUTDB ? d.max_db + e + 1
                                     : pk == OCRGPU_PAY_DEPV ? (sl[sc.payload] & 0x7FFFFFFFu) : 0u;
+                            if (sc.op_kind & 0x10000u) { // the event lives on another partition
+                                RemoteDst rd = d.rdst[sc.target]; emit_remote(d, rd.guid, rd.slot, 0u, pay); continue;
+                            }
                             u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
                             if (qi < d.q_cap) d.q[qi] = Rec{sc.target, pay, sc.slot, 0u};
                             else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
+                        } else if (sc.op_kind & 0x10000u) { // ocrEventDestroy of a remote event
+                            RemoteDst rd = d.rdst[sc.target]; emit_remote(d, rd.guid, 0u, XF_DESTROY, 0u);
                         } else { // ocrEventDestroy
                             u32 old = atomicExch(evt_state(d, sc.target), (u32)ST_DESTROYED);
                             if ((old & 0xFF) != ST_LIVE && (old & 0xFF) != ST_SAT) atomicAdd(&c->err[ERR_DEAD_EVENT], 1u);
@@ -444,18 +493,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (total) fan_out<NANNY>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             else __syncthreads();
             STAMP(3);
-            if (mine) { // the body proper: fold id + every depv[k] payload (8 pre-slots per round of loads)
-                u64 v = ocrops_hash_init(id);
-                for (u32 k0 = 0; k0 < depc; k0 += 8) {
-                    if (k0) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, k0 + k < depc ? (sl[k0 + k] & 0x7FFFFFFFu) : 0u);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) if (k0 + k < depc) v = ocrops_hash_step(v, k0 + k, gb[k].x, gb[k].y + 1);
-                }
-                d.edt[e].val = v; // == the output DB's value (a live DB only for HASH bodies)
-            }
+            if (mine && !body_first) run_body(d, e, id, depc, sl, gb);
         }
     } else {
         // ---- queued satisfies: API calls, fired chained events, big-row pieces, direct EDT pre-slot satisfies ----
@@ -618,7 +656,30 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
     if (i >= n) return;
     u64 s = src[i];
     u32 didx, dslot, dflag;
-    if (!resolve_dst(d, dst[i], slot[i], didx, dflag, dslot)) { bad_op(d); return; }
+    const u64 dg = dst[i];
+    if (d.n_loc > 1 && dg != 0 && dg < TOMB - 1 && OCRGPU_GUID_LOCATION(dg) != d.location) {
+        // destination owned by another partition: the waiter stays with the (local) source event, the satisfy
+        // crosses as a SendRec; the owner resolves slot encoding and mode when it applies it
+        const u32 dk = OCRGPU_GUID_KIND(dg);
+        const bool r_edt = dk == OCRGPU_KIND_EDT;
+        if (!r_edt && !is_event_kind(dk)) { bad_op(d); return; }
+        const u32 xf = (r_edt && mode[i] == OCRMODE_NULL) ? XF_MODE_NULL : 0u;
+        if (s == OCRGPU_NULL_GUID) { emit_remote(d, dg, slot[i], xf, 0u); return; }
+        u64 sv = gtab_get(d, s); u32 sk = OCRGPU_GUID_KIND(s);
+        if (!sv) { atomicAdd(&d.ctrl->err[is_event_kind(sk) ? ERR_LATE_WAITER : ERR_BAD_OP], 1u); return; }
+        if (sk == OCRGPU_KIND_DB) { emit_remote(d, dg, slot[i], xf, (u32)sv); return; }
+        if (!is_event_kind(sk)) { bad_op(d); return; }
+        u32 x = (u32)(sv - 1), st = *evt_state(d, x) & 0xFF;
+        if (st == ST_SAT) { emit_remote(d, dg, slot[i], xf, (u32)*evt_val(d, x)); return; }
+        if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }
+        u32 ri = atomicAdd(&d.ctrl->rdst_tail, 1u), li = atomicAdd(&d.ctrl->log_tail, 1u);
+        if (ri >= d.rdst_cap || li >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+        d.rdst[ri] = RemoteDst{dg, slot[i], xf};
+        d.log_src[li] = x;
+        d.log_rec[li] = ((u64)(RF_REMOTE << 28) << 32) | (u64)ri;
+        return;
+    }
+    if (!resolve_dst(d, dg, slot[i], didx, dflag, dslot)) { bad_op(d); return; }
     const bool d_edt = (dflag & RF_DST_EDT) != 0;
     u32 mnull = (d_edt && mode[i] == OCRMODE_NULL) ? RF_MODE_NULL : 0u;
     if (s == OCRGPU_NULL_GUID) { q_push(d, Rec{didx, 0u, dslot, dflag}); return; } // == satisfy(dst, slot, NULL)
@@ -657,6 +718,11 @@ __global__ void k_satisfy(Dev d, u64 n, const u64 *evt, const u64 *db, const u32
     if (i >= n) return;
     u64 g = evt[i];
     if (g == OCRGPU_NULL_GUID) return; // ocrEventSatisfy(NULL_GUID, ..) is a no-op (ocr-edt.c:171)
+    if (d.n_loc > 1 && g < TOMB - 1 && OCRGPU_GUID_LOCATION(g) != d.location) { // satisfy of a remote event
+        u32 pay = 0;
+        if (db[i] != OCRGPU_NULL_GUID) { u64 v = gtab_get(d, db[i]); if (!v) { bad_op(d); return; } pay = (u32)v; }
+        emit_remote(d, g, slot[i], 0u, pay); return;
+    }
     u32 didx, dslot, dflag;
     if (!resolve_dst(d, g, slot[i], didx, dflag, dslot)) { bad_op(d); return; }
     u32 pay = 0;
@@ -686,11 +752,49 @@ __global__ void k_script_ops(Dev d, u64 n, const ocrgpu_script_op_t *ops, u32 sc
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     ocrgpu_script_op_t o = ops[i];
-    u64 v = gtab_get(d, o.target);
-    if (!v || !is_event_kind(OCRGPU_GUID_KIND(o.target))) { bad_op(d); v = 1; }
+    u32 remote = 0;
+    u64 v;
+    if (d.n_loc > 1 && o.target != 0 && o.target < TOMB - 1 && OCRGPU_GUID_LOCATION(o.target) != d.location && is_event_kind(OCRGPU_GUID_KIND(o.target))) {
+        u32 ri = atomicAdd(&d.ctrl->rdst_tail, 1u);
+        if (ri >= d.rdst_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); ri = 0; }
+        else d.rdst[ri] = RemoteDst{o.target, o.slot, 0u};
+        v = (u64)ri + 1; remote = 0x10000u;
+    } else {
+        v = gtab_get(d, o.target);
+        if (!v || !is_event_kind(OCRGPU_GUID_KIND(o.target))) { bad_op(d); v = 1; }
+    }
     u32 pay = (u32)o.payload;
     if (o.payload_kind == OCRGPU_PAY_GUID) { u64 pv = gtab_get(d, o.payload); if (!pv) bad_op(d); pay = (u32)pv; }
-    d.scripts[script_base + i] = Script{(u32)(v - 1), pay, o.slot, (u32)o.op | ((u32)o.payload_kind << 8)};
+    d.scripts[script_base + i] = Script{(u32)(v - 1), pay, o.slot, (u32)o.op | ((u32)o.payload_kind << 8) | remote};
+}
+
+// Apply satisfies received from other partitions: resolve the guid in OUR table, clone the DB into a proxy
+// entry, and queue an ordinary record (the next EVENTS phase does the rest).
+__global__ void k_exchange_apply(Dev d, u64 n, const SendRec *recs, u32 proxy_base) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SendRec r = recs[i];
+    if (r.flags & XF_DESTROY) {
+        u64 v = (OCRGPU_GUID_LOCATION(r.guid) == d.location && is_event_kind(OCRGPU_GUID_KIND(r.guid))) ? gtab_get(d, r.guid) : 0;
+        if (!v) { bad_op(d); return; }
+        u32 old = atomicExch(evt_state(d, (u32)(v - 1)), (u32)ST_DESTROYED);
+        if ((old & 0xFF) != ST_LIVE && (old & 0xFF) != ST_SAT) atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
+        return;
+    }
+    u32 didx, dslot, dflag;
+    if (OCRGPU_GUID_LOCATION(r.guid) != d.location || !resolve_dst(d, r.guid, r.slot, didx, dflag, dslot)) { bad_op(d); return; }
+    u32 pay = 0;
+    if (r.flags & XF_HAS_DB) { d.db[proxy_base + i] = make_ulonglong2(r.value, r.tag); pay = proxy_base + (u32)i + 1; }
+    if ((dflag & RF_DST_EDT) && (r.flags & XF_MODE_NULL)) dflag |= RF_MODE_NULL;
+    q_push(d, Rec{didx, pay, dslot, dflag});
+}
+__global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
+__global__ void k_exchange_counts(Dev d, u32 *out) { if (threadIdx.x < d.n_loc) { u32 c = d.send_cnt[threadIdx.x * 32]; out[threadIdx.x] = c > d.send_cap ? d.send_cap : c; } }
+// an empty level on this partition (others may have fired): keep the global level numbering aligned
+__global__ void k_bump_level(Dev d) {
+    Ctrl *c = d.ctrl;
+    u32 nl = c->level + 1; c->level = nl; c->n_levels = nl + 1;
+    if (nl < d.max_levels) { d.level_start[nl] = c->r_end; d.level_start[nl + 1] = c->r_end; } else c->err[ERR_LEVEL_OVERFLOW]++;
 }
 
 // ---- CSR (re)build from the registration log: count -> scan -> fill --------------------------------
@@ -825,7 +929,7 @@ struct ocrgpu_engine {
     u32 *tmp_a, *tmp_b, *tmp_c; // scan temporaries sized for max(max_edt, n_evt_total)
     u32 *scan_partials; u64 scan_partials_cap;
     Snapshot snap;
-    hipEvent_t ev0, ev1; bool have_events; u32 step_grid; u32 launch_index; u64 fired_cap;
+    hipEvent_t ev0, ev1; bool have_events; u32 step_grid; u32 launch_index; u64 fired_cap; bool defer_drain; u32 *send_cnt_dev;
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
     u32 *pinned_done;
 };
@@ -927,7 +1031,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->have_events = false;
-    e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
+    e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
     d.max_edt = cfg->max_edt; d.max_evt = cfg->max_evt; d.max_db = cfg->max_db; d.location = cfg->location;
     d.max_slots = cfg->max_slots ? cfg->max_slots : 1; d.max_edges = cfg->max_edges ? cfg->max_edges : 1;
@@ -1030,12 +1134,12 @@ static int seal(ocrgpu_engine *e) {
 }
 
 // ---- drain: run k_step launches until the device says done ---------------------------------------------
-static int run_steps(ocrgpu_engine *e, bool allow_fire, u64 max_launches, bool timing) {
+static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool timing) {
     Dev &d = e->d;
     int r = seal(e); if (r) return r;
     if (e->launch_index > 0xFFFF0000u) e->launch_index = 8; // keep K-1 and K%3 arithmetic away from the wrap
     u32 K = e->launch_index + 1;
-    k_begin<<<1, 1, 0, e->stream>>>(d, K, allow_fire ? 1u : 0u);
+    k_begin<<<1, 1, 0, e->stream>>>(d, K, allow_fire);
     const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
     const u32 grid = e->step_grid > MAX_GRID ? MAX_GRID : (e->step_grid ? e->step_grid : 256u);
     u32 batch = allow_fire ? 8 : 2;
@@ -1064,12 +1168,13 @@ static int run_steps(ocrgpu_engine *e, bool allow_fire, u64 max_launches, bool t
     return 0;
 }
 static int drain_events(ocrgpu_engine *e) {
+    if (e->defer_drain) return 0; // distributed stepping: the driver calls ocrgpu_step
     // q_begin and q_tail sit in different cache lines of Ctrl: two 4-byte reads, one sync
     HIPCHK(hipMemcpyAsync(e->pinned_done + 8, &e->d.ctrl->q_begin, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(e->pinned_done + 9, &e->d.ctrl->q_tail, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->pinned_done[9] <= e->pinned_done[8]) return 0; // nothing queued: registrations only
-    return run_steps(e, false, ~0ull, false);
+    return run_steps(e, 0u, ~0ull, false);
 }
 
 // ---- GUID provider -----------------------------------------------------------------------------------------
@@ -1253,11 +1358,80 @@ static int fetch_stats(ocrgpu_engine *e, ocrgpu_stats_t *out) {
 extern "C" int ocrgpu_resolve(ocrgpu_engine_t *e, u64 max_levels, ocrgpu_stats_t *stats_out) {
     ENTER(e);
     u64 max_launches = max_levels ? 4 * max_levels + 64 : ~0ull;
-    int r = run_steps(e, true, max_launches, true);
+    int r = run_steps(e, 0xFFFFFFFFu, max_launches, true);
     if (r) return r;
     if (stats_out) { r = fetch_stats(e, stats_out); if (r) return r; e->last = *stats_out; }
     return 0;
 }
+extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *has_ready_out, u64 *pending_records_out) {
+    ENTER(e);
+    Dev &d = e->d;
+    // anything to fire?  (log entries beyond the last fired level; may be holes only, which is harmless)
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 8, &d.ctrl->r_end, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 9, &d.ctrl->r_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    bool ready_before = e->pinned_done[9] > e->pinned_done[8];
+    if (fire_levels && !ready_before && (flags & OCRGPU_STEP_FORCE_LEVEL)) {
+        int r0 = run_steps(e, 0u, ~0ull, false); if (r0) return r0; // close pending event chains first
+        k_bump_level<<<1, 1, 0, e->stream>>>(d);
+    } else {
+        int r = run_steps(e, fire_levels, ~0ull, true); if (r) return r;
+    }
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 8, &d.ctrl->r_end, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 9, &d.ctrl->r_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 10, &d.ctrl->q_begin, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 11, &d.ctrl->q_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (has_ready_out) *has_ready_out = e->pinned_done[9] > e->pinned_done[8] ? 1 : 0;
+    if (pending_records_out) *pending_records_out = e->pinned_done[11] > e->pinned_done[10] ? e->pinned_done[11] - e->pinned_done[10] : 0;
+    return 0;
+}
+
+// ---- cross-partition exchange (replaces the comm-platform's sendMessage/pollMessage for DEP_SATISFY,
+//      ocr/src/inc/ocr-comm-platform.h:55-199; the transport itself -- RCCL all-to-all -- is the caller's) ----
+extern "C" int ocrgpu_exchange_config(ocrgpu_engine_t *e, u32 n_locations, void *send_dev_buf, u64 records_per_dest, u64 max_remote_dsts) {
+    ENTER(e);
+    if (n_locations == 0 || n_locations > 1024 || e->cfg.location >= n_locations) FAIL(OCRGPU_EINVAL, "bad n_locations");
+    if (n_locations > 1 && (!send_dev_buf || records_per_dest == 0 || records_per_dest > 0xFFFFFFFFull)) FAIL(OCRGPU_EINVAL, "send buffer required");
+    Dev &d = e->d;
+    d.n_loc = n_locations; d.send = (SendRec *)send_dev_buf; d.send_cap = (u32)records_per_dest;
+    if (!e->send_cnt_dev) { int r = dalloc(e, (void **)&e->send_cnt_dev, 4 * 32 * 1024); if (r) return r; }
+    d.send_cnt = e->send_cnt_dev;
+    if (max_remote_dsts && !d.rdst) { int r = dalloc(e, (void **)&d.rdst, sizeof(RemoteDst) * (size_t)max_remote_dsts); if (r) return r; d.rdst_cap = (u32)max_remote_dsts; }
+    e->defer_drain = n_locations > 1; // records may target other partitions: the distributed driver steps explicitly
+    return 0;
+}
+extern "C" int ocrgpu_exchange_counts(ocrgpu_engine_t *e, u32 *counts_out) {
+    ENTER(e);
+    if (!counts_out || !e->d.send_cnt) FAIL(OCRGPU_EINVAL, "exchange not configured");
+    int r = stage_reserve(e, 4096 + 256); if (r) return r;
+    u32 *dc = (u32 *)e->stage_dev;
+    k_exchange_counts<<<1, 1024, 0, e->stream>>>(e->d, dc);
+    HIPCHK(hipMemcpyAsync(counts_out, dc, 4 * e->d.n_loc, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_exchange_reset(ocrgpu_engine_t *e) {
+    ENTER(e);
+    if (!e->d.send_cnt) FAIL(OCRGPU_EINVAL, "exchange not configured");
+    k_exchange_reset<<<1, 1024, 0, e->stream>>>(e->d);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int ocrgpu_exchange_apply(ocrgpu_engine_t *e, const void *recs, u64 n, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!recs) FAIL(OCRGPU_EINVAL, "null records");
+    if ((u64)e->n_db + n > e->cfg.max_db) FAIL(OCRGPU_ENOMEM, "max_db=%u exhausted by proxy datablocks", e->cfg.max_db);
+    int r = stage_reserve(e, rup(32 * n)); if (r) return r;
+    const SendRec *dr; if ((r = stage_in(e, (const SendRec *)recs, n, where, &dr))) return r;
+    k_exchange_apply<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dr, e->n_db);
+    e->n_db += (u32)n;
+    HIPCHK(hipGetLastError());
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 extern "C" int ocrgpu_get_stats(ocrgpu_engine_t *e, ocrgpu_stats_t *out) { ENTER(e); if (!out) FAIL(OCRGPU_EINVAL, "null"); return fetch_stats(e, out); }
 
 extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {

@@ -1,0 +1,365 @@
+"""GUID-space partitioning across GPUs: one engine per rank, cross-partition satisfies batched per level.
+
+This is the host-side plumbing that takes the place of the reference's distributed policy domain + MPI
+comm-platform (ocr/src/policy-domain/hc-dist/hc-dist-policy.c:1027-1031,2208; ocr/src/comm-platform/mpi/
+mpi-comm-platform.c:1055) for PD_MSG_DEP_SATISFY: instead of one marshalled ocrPolicyMsg_t per remote satisfy,
+every engine fills per-destination buffers of 32-byte records during a level, and the ranks exchange them with
+ONE all-to-all per round (RCCL over xGMI through torch.distributed; device-to-device copies when several
+partitions share one process, which is how the single-GPU tests exercise the same code).
+
+Ownership: an object lives on the rank named by its GUID's LOCHOME bits (ocr/src/guid/guid-bitmap-based.c:25-58).
+``owner_of`` decides it per logical index; an EDT's output event and output DB live with the EDT.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import opstream as ops
+from .engine import SCRIPT_OP_DT, Engine
+from .opstream import OpStream, Result
+
+REC_BYTES = 32
+KIND_DB, KIND_EDT = 2, 3
+EVT_GUID_KIND = {ops.EVT_ONCE: 17, ops.EVT_COUNTED: 18, ops.EVT_IDEM: 19, ops.EVT_STICKY: 21, ops.EVT_LATCH: 22,
+                 ops.EVT_CHANNEL: 23}
+
+
+def mkguid(loc, kind, counter):
+    return (np.uint64(loc) << np.uint64(54)) | (np.asarray(kind, np.uint64) << np.uint64(49)) | np.asarray(counter, np.uint64)
+
+
+def default_owner(idx, world):
+    """Hash partition of a logical index (Fibonacci hash of the index, top bits)."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return ((idx * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)) % np.uint64(world)
+
+
+class Partition:
+    """One rank's share of an op stream.  Every rank walks the same main-op list and executes the ops whose
+    executor it is: creations by the owner, ocrAddDependence by the owner of the source (the waiter list lives
+    with the source event), NULL-source add-deps by the owner of the destination, satisfies by the owner of the
+    payload DB (else of the event).  GUIDs of remote objects are predicted: every engine hands out counters in
+    creation order, so all ranks can compute all GUIDs from the stream alone (checked against the real ones)."""
+
+    def __init__(self, s: OpStream, rank: int, world: int, device=0, flags=0, send_cap=None, torch=None):
+        import torch as _torch
+        self.torch = torch or _torch
+        self.s, self.rank, self.world = s, rank, world
+        self.own_edt = default_owner(np.arange(s.n_edt), world).astype(np.int64)
+        self.own_evt = default_owner(np.arange(s.n_evt) + (1 << 40), world).astype(np.int64)
+        self.own_db = default_owner(np.arange(s.n_db) + (2 << 40), world).astype(np.int64)
+        self._predict_guids()
+        mine_e = self.own_edt == rank
+        n_my_edt = int(mine_e.sum())
+        n_adddep = int((s.main["op"] == ops.OP_ADD_DEP).sum())
+        cap = send_cap or max(4096, n_adddep + len(s.script) + 1024)
+        self.send_cap = cap
+        self.send = self.torch.zeros((world, cap, REC_BYTES), dtype=self.torch.uint8, device=f"cuda:{device}")
+        self.eng = Engine(max_edt=max(n_my_edt, 1), max_evt=max(int((self.own_evt == rank).sum()), 1),
+                          max_db=max(int((self.own_db == rank).sum()), 1) + world * cap + 16,
+                          max_slots=int(s.edt["depc"][mine_e].sum()) + 1, max_edges=n_adddep + 1, device=device,
+                          location=rank, flags=flags)
+        self.eng.exchange_config(world, self.send.data_ptr(), cap, n_adddep + len(s.script) + 16)
+        self.eng.set_hash_tag_base(s.n_db)
+        self.my_edts = np.nonzero(mine_e)[0]          # in creation order == engine index order (checked in build)
+        self._created = np.zeros(s.n_edt, dtype=bool)
+        self.my_evts, self.my_dbs = [], []
+
+    # -- GUID prediction: replay every rank's creation counters --
+    def _predict_guids(self):
+        s, W = self.s, self.world
+        self.edt_guid = np.zeros(s.n_edt, np.uint64)
+        self.evt_guid = np.zeros(s.n_evt_total, np.uint64)
+        self.db_guid = np.zeros(s.n_db_total, np.uint64)
+        counter = np.ones(W, np.int64)
+        main = s.main
+        if not len(main):
+            return
+        cuts = np.nonzero(np.diff(main["op"].astype(np.int16)))[0] + 1
+        for b0, b1 in zip(np.r_[0, cuts], np.r_[cuts, len(main)]):
+            op = int(main["op"][b0])
+            if op not in (ops.OP_EVT_CREATE, ops.OP_DB_CREATE, ops.OP_EDT_CREATE):
+                continue
+            idx = main["a"][b0:b1].astype(np.int64)
+            own = {ops.OP_EVT_CREATE: self.own_evt, ops.OP_DB_CREATE: self.own_db, ops.OP_EDT_CREATE: self.own_edt}[op][idx]
+            step = 3 if op == ops.OP_EDT_CREATE else 1
+            for r in range(W):
+                m = own == r
+                k = int(m.sum())
+                if not k:
+                    continue
+                c = counter[r] + step * np.arange(k, dtype=np.int64)
+                ii = idx[m]
+                if op == ops.OP_EVT_CREATE:
+                    kinds = np.array([EVT_GUID_KIND[int(x)] for x in s.evt["kind"][ii]], np.uint64)
+                    self.evt_guid[ii] = mkguid(r, kinds, c)
+                elif op == ops.OP_DB_CREATE:
+                    self.db_guid[ii] = mkguid(r, KIND_DB, c)
+                else:
+                    self.edt_guid[ii] = mkguid(r, KIND_EDT, c)
+                    has_oe = (s.edt["body"][ii] & ops.BODY_F_OUTEVT) != 0
+                    self.evt_guid[s.n_evt + ii] = np.where(has_oe, mkguid(r, 17, c + 1), np.uint64(0))
+                    self.db_guid[s.n_db + ii] = mkguid(r, KIND_DB, c + 2)
+                counter[r] += step * k
+
+    def _guids(self, refs):
+        refs = np.asarray(refs, dtype=np.uint64)
+        cls, idx = ops.ref_cls(refs), ops.ref_idx(refs).astype(np.int64)
+        out = np.zeros(len(refs), np.uint64)
+        s = self.s
+        for c, table, base in ((ops.REF_EDT, self.edt_guid, 0), (ops.REF_EVT, self.evt_guid, 0),
+                               (ops.REF_OUTEVT, self.evt_guid, s.n_evt), (ops.REF_DB, self.db_guid, 0),
+                               (ops.REF_OUTDB, self.db_guid, s.n_db)):
+            m = cls == c
+            if m.any():
+                out[m] = table[idx[m] + base]
+        return out
+
+    def _owner_of_refs(self, refs):
+        """Owner rank of each ref (-1 for NULL)."""
+        refs = np.asarray(refs, dtype=np.uint64)
+        cls, idx = ops.ref_cls(refs), ops.ref_idx(refs).astype(np.int64)
+        out = np.full(len(refs), -1, np.int64)
+        for c, own in ((ops.REF_EDT, self.own_edt), (ops.REF_OUTEVT, self.own_edt), (ops.REF_OUTDB, self.own_edt),
+                       (ops.REF_EVT, self.own_evt), (ops.REF_DB, self.own_db)):
+            m = cls == c
+            if m.any():
+                out[m] = own[idx[m]]
+        return out
+
+    def build(self, sync=None):
+        """Replay the main ops.  ``sync()`` is called after every batch that may have produced cross-partition
+        records (all ranks reach the same points: the batch boundaries depend on the stream only), so the main
+        program's satisfies are delivered in program order."""
+        for _ in self.build_steps():
+            if sync is not None:
+                sync()
+        return self
+
+    def build_steps(self):
+        s, eng, me = self.s, self.eng, self.rank
+        main = s.main
+        scripts_done = len(s.script) == 0
+        if len(main):
+            cuts = np.nonzero(np.diff(main["op"].astype(np.int16)))[0] + 1
+            bounds = list(zip(np.r_[0, cuts], np.r_[cuts, len(main)]))
+        else:
+            bounds = []
+        for b0, b1 in bounds:
+            blk = main[b0:b1]
+            op = int(blk["op"][0])
+            if op == ops.OP_EVT_CREATE:
+                idx = blk["a"].astype(np.int64)
+                idx = idx[self.own_evt[idx] == me]
+                if len(idx):
+                    g = eng.event_create(s.evt["kind"][idx], s.evt["arg"][idx])
+                    assert np.array_equal(g, self.evt_guid[idx]), "GUID prediction drifted (events)"
+                    self.my_evts += idx.tolist()
+            elif op == ops.OP_DB_CREATE:
+                idx = blk["a"].astype(np.int64)
+                idx = idx[self.own_db[idx] == me]
+                if len(idx):
+                    g = eng.db_create(s.db_init[idx], idx.astype(np.uint64))
+                    assert np.array_equal(g, self.db_guid[idx]), "GUID prediction drifted (DBs)"
+                    self.my_dbs += idx.tolist()
+            elif op == ops.OP_EDT_CREATE:
+                idx = blk["a"].astype(np.int64)
+                idx = idx[self.own_edt[idx] == me]
+                if len(idx):
+                    g, oe, od = eng.edt_create(s.edt["depc"][idx], s.edt["body"][idx], idx.astype(np.uint64))
+                    assert np.array_equal(g, self.edt_guid[idx]) and np.array_equal(oe, self.evt_guid[s.n_evt + idx]) \
+                        and np.array_equal(od, self.db_guid[s.n_db + idx]), "GUID prediction drifted (EDTs)"
+                    self._created[idx] = True
+            elif op == ops.OP_ADD_DEP:
+                so, do = self._owner_of_refs(blk["a"]), self._owner_of_refs(blk["b"])
+                m = np.where(so >= 0, so, do) == me
+                if m.any():
+                    b = blk[m]
+                    eng.add_dependence(self._guids(b["a"]), self._guids(b["b"]), b["slot"], b["mode"].astype(np.uint32))
+                yield op
+            elif op == ops.OP_SATISFY:
+                if not scripts_done and self._scripted_edts_exist():
+                    self._set_scripts(); scripts_done = True
+                for c0, c1 in ops.split_conflicts(blk["a"]):   # two satisfies of one event keep program order
+                    sub = blk[c0:c1]
+                    po, eo = self._owner_of_refs(sub["b"]), self._owner_of_refs(sub["a"])
+                    m = np.where(po >= 0, po, eo) == me
+                    if m.any():
+                        b = sub[m]
+                        eng.event_satisfy_slot(self._guids(b["a"]), self._guids(b["b"]), b["slot"])
+                    yield op
+            elif op == ops.OP_EVT_DESTROY:
+                m = self._owner_of_refs(blk["a"]) == me
+                if m.any():
+                    eng.event_destroy(self._guids(blk["a"][m]))
+                yield op
+        if not scripts_done:
+            self._set_scripts()
+
+    def _scripted_edts_exist(self):
+        s = self.s
+        has = np.nonzero((s.edt["script_len"] > 0) & (self.own_edt == self.rank))[0]
+        return bool(np.all(self._created[has])) if len(has) else True
+
+    def _set_scripts(self):
+        s = self.s
+        has = np.nonzero((s.edt["script_len"] > 0) & (self.own_edt == self.rank))[0]
+        if not len(has):
+            return
+        # re-pack the scripts of the EDTs this rank owns
+        begins, lens, rows = [], [], []
+        for e in has:
+            b, n = int(s.edt["script_begin"][e]), int(s.edt["script_len"][e])
+            begins.append(len(rows)); lens.append(n); rows += list(range(b, b + n))
+        sub = s.script[np.asarray(rows, dtype=np.int64)]
+        sc = np.zeros(len(sub), dtype=SCRIPT_OP_DT)
+        sc["target"], sc["slot"], sc["op"] = self._guids(sub["a"]), sub["slot"], sub["op"]
+        cls = ops.ref_cls(sub["b"])
+        pk, pay = np.zeros(len(sc), np.uint8), np.zeros(len(sc), np.uint64)
+        m = cls == ops.REF_DB
+        if m.any():
+            assert np.all(self._owner_of_refs(sub["b"][m]) == self.rank), "script payload DB must live with the EDT"
+            pk[m], pay[m] = 1, self._guids(sub["b"][m])
+        pk[cls == ops.REF_OUTDB] = 2
+        m = cls == ops.REF_DEPV
+        pk[m], pay[m] = 3, ops.ref_idx(sub["b"][m])
+        sc["payload_kind"], sc["payload"] = pk, pay
+        self.eng.edt_set_scripts(self.edt_guid[has], np.asarray(begins, np.uint32), np.asarray(lens, np.uint32), sc)
+
+    # -- the per-level protocol --
+    def fire_one_level(self):
+        return self.eng.step(1, force_level=True)
+
+    def drain(self):
+        return self.eng.step(0)
+
+    def outgoing(self):
+        return self.eng.exchange_counts().astype(np.int64)
+
+    def fill_result(self, level, val, evs, dbv):
+        """Write this rank's objects into the global result arrays."""
+        s, eng = self.s, self.eng
+        n = len(self.my_edts)
+        if n:
+            lv, v = eng.read_edts(0, n)
+            level[self.my_edts], val[self.my_edts] = lv, v
+            evs[s.n_evt + self.my_edts] = eng.read_events(1, 0, n)
+            dbv[s.n_db + self.my_edts] = eng.read_dbs(1, 0, n)
+        if self.my_evts:
+            evs[np.asarray(self.my_evts)] = eng.read_events(0, 0, len(self.my_evts))
+        if self.my_dbs:
+            dbv[np.asarray(self.my_dbs)] = eng.read_dbs(0, 0, len(self.my_dbs))
+
+
+def _lockstep_exchange(parts):
+    torch = parts[0].torch
+    W = len(parts)
+    if True:
+        for p in parts:
+            p.drain()                                                 # close local event chains first
+        while True:
+            counts = np.stack([p.outgoing() for p in parts])         # counts[src][dst]
+            if counts.sum() == 0:
+                return
+            inbox = []
+            for dst in range(W):
+                chunks = [parts[src].send[dst, :int(counts[src][dst])] for src in range(W) if counts[src][dst]]
+                inbox.append(torch.cat(chunks).contiguous() if chunks else None)
+            for p in parts:
+                p.eng.exchange_reset()
+            for dst, p in enumerate(parts):
+                if inbox[dst] is not None:
+                    p.eng.exchange_apply(inbox[dst].data_ptr(), inbox[dst].shape[0])
+                p.drain()
+
+
+def build_lockstep(parts):
+    """Build every partition in lockstep, exchanging after each dependence / satisfy batch."""
+    gens = [p.build_steps() for p in parts]
+    while True:
+        alive = [next(g, None) is not None for g in gens]
+        assert all(alive) or not any(alive), "partitions walked different batch sequences"
+        if not any(alive):
+            return parts
+        _lockstep_exchange(parts)
+
+
+def resolve_lockstep(parts):
+    """Drive several partitions that live in ONE process (tests: all on one GPU).  Same protocol as
+    :func:`resolve_distributed`, with device-to-device copies standing in for the all-to-all."""
+    levels = 0
+    _lockstep_exchange(parts)
+    while any(p.eng.step(0)[0] for p in parts):
+        for p in parts:
+            p.fire_one_level()
+        levels += 1
+        _lockstep_exchange(parts)
+    return levels
+
+
+def exchange_records(dist, send, counts, device):
+    """all-to-all-v of 32-byte records: ``send[dst, :counts[dst]]`` goes to rank dst. Returns (recv tensor, n)."""
+    import torch
+    W = dist.get_world_size()
+    cnt_out = torch.as_tensor(np.asarray(counts, dtype=np.int64), device=device)
+    cnt_in = torch.empty_like(cnt_out)
+    dist.all_to_all_single(cnt_in, cnt_out)
+    cin = cnt_in.cpu().numpy()
+    sendbuf = torch.cat([send[d, :int(counts[d])] for d in range(W)]) if int(np.sum(counts)) else send[0, :0]
+    recv = torch.empty((int(cin.sum()), REC_BYTES), dtype=torch.uint8, device=device)
+    dist.all_to_all_single(recv, sendbuf.contiguous(), output_split_sizes=[int(x) for x in cin],
+                           input_split_sizes=[int(x) for x in counts])
+    return recv, int(cin.sum())
+
+
+def distributed_exchange(part: Partition, dist):
+    """Rounds of [count all-reduce, all-to-all-v, apply, drain] until no record is in flight on any rank."""
+    import torch
+    dev = part.send.device
+    part.drain()
+    while True:
+        counts = part.outgoing()
+        tot = torch.tensor([int(counts.sum())], device=dev, dtype=torch.int64)
+        dist.all_reduce(tot)
+        if int(tot.item()) == 0:
+            return
+        recv, n = exchange_records(dist, part.send, counts, dev)
+        part.eng.exchange_reset()
+        if n:
+            part.eng.exchange_apply(recv.data_ptr(), n)
+        part.drain()
+
+
+def resolve_distributed(part: Partition, dist):
+    """One process per GPU (torch.distributed, backend "nccl" == RCCL): deliver the main program's remote
+    satisfies, then per level one FIRE step followed by rounds of [counts all-to-all + record all-to-all + apply +
+    drain] until no record is in flight anywhere; one all-reduce per level decides whether anybody can still fire."""
+    import torch
+    dev = part.send.device
+
+    def exchange_rounds():
+        distributed_exchange(part, dist)
+
+    def anybody_ready():
+        flag = torch.tensor([1 if part.eng.step(0)[0] else 0], device=dev, dtype=torch.int64)
+        dist.all_reduce(flag)
+        return int(flag.item()) != 0
+
+    levels = 0
+    exchange_rounds()
+    while anybody_ready():
+        part.fire_one_level()
+        levels += 1
+        exchange_rounds()
+    return levels
+
+
+def gather_result_lockstep(s: OpStream, parts) -> Result:
+    level = np.full(s.n_edt, -1, np.int32)
+    val = np.zeros(s.n_edt, np.uint64)
+    evs = np.full(s.n_evt_total, ops.EVS_ABSENT, np.uint64)
+    dbv = np.zeros(s.n_db_total, np.uint64)
+    for p in parts:
+        p.fill_result(level, val, evs, dbv)
+    return Result(level, val, evs, dbv)

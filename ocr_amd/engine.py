@@ -52,7 +52,8 @@ EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error
            "ocrgpu_guid_reserve", "ocrgpu_guid_put", "ocrgpu_guid_get", "ocrgpu_guid_remove",
            "ocrgpu_event_create", "ocrgpu_db_create", "ocrgpu_edt_create", "ocrgpu_edt_set_scripts",
            "ocrgpu_set_hash_tag_base", "ocrgpu_add_dependence", "ocrgpu_event_satisfy_slot", "ocrgpu_event_destroy",
-           "ocrgpu_resolve", "ocrgpu_snapshot", "ocrgpu_restore", "ocrgpu_sync", "ocrgpu_read_edts",
+           "ocrgpu_resolve", "ocrgpu_step", "ocrgpu_exchange_config", "ocrgpu_exchange_counts",
+           "ocrgpu_exchange_reset", "ocrgpu_exchange_apply", "ocrgpu_snapshot", "ocrgpu_restore", "ocrgpu_sync", "ocrgpu_read_edts",
            "ocrgpu_read_events", "ocrgpu_read_dbs", "ocrgpu_read_fired", "ocrgpu_get_stats"]
 
 _lib = None
@@ -191,6 +192,30 @@ class Engine:
         self._chk(self.lib.ocrgpu_resolve(self.h, C.c_uint64(max_levels), C.byref(st)))
         return st
 
+    def step(self, fire_levels=1, force_level=False):
+        """Fire at most ``fire_levels`` levels then stop. Returns (has_ready, pending_records)."""
+        hr, pr = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.ocrgpu_step(self.h, C.c_uint32(fire_levels), C.c_uint32(1 if force_level else 0),
+                                       C.byref(hr), C.byref(pr)))
+        return bool(hr.value), int(pr.value)
+
+    # ---- cross-partition exchange ----
+    def exchange_config(self, n_locations, send_dev_ptr, records_per_dest, max_remote_dsts):
+        self.n_locations = n_locations
+        self._chk(self.lib.ocrgpu_exchange_config(self.h, C.c_uint32(n_locations), C.c_void_p(send_dev_ptr),
+                                                  C.c_uint64(records_per_dest), C.c_uint64(max_remote_dsts)))
+
+    def exchange_counts(self):
+        out = np.zeros(self.n_locations, np.uint32)
+        self._chk(self.lib.ocrgpu_exchange_counts(self.h, _ptr(out)))
+        return out
+
+    def exchange_reset(self):
+        self._chk(self.lib.ocrgpu_exchange_reset(self.h))
+
+    def exchange_apply(self, dev_ptr, n):
+        self._chk(self.lib.ocrgpu_exchange_apply(self.h, C.c_void_p(dev_ptr), C.c_uint64(n), DEVICE))
+
     def snapshot(self):
         self._chk(self.lib.ocrgpu_snapshot(self.h))
 
@@ -292,7 +317,9 @@ class StreamProgram:
                 eng.add_dependence(self._guids(blk["a"]), self._guids(blk["b"]), blk["slot"], blk["mode"].astype(np.uint32))
             elif op == ops.OP_SATISFY:
                 self._set_scripts()
-                eng.event_satisfy_slot(self._guids(blk["a"]), self._guids(blk["b"]), blk["slot"])
+                for c0, c1 in ops.split_conflicts(blk["a"]):   # two satisfies of one event keep program order
+                    b = blk[c0:c1]
+                    eng.event_satisfy_slot(self._guids(b["a"]), self._guids(b["b"]), b["slot"])
             elif op == ops.OP_EVT_DESTROY:
                 eng.event_destroy(self._guids(blk["a"]))
             else:

@@ -377,3 +377,19 @@ class Builder:
             return out
         return OpStream(edt, evt, np.array(self.dbs, dtype=np.uint64), pack(self.main), pack(script), sink_edt,
                         name=self.name)
+
+
+def split_conflicts(keys):
+    """Cut points for a run of ops so that no non-zero key repeats inside one sub-batch (ops of one batch are
+    unordered on the GPU; two satisfies of the SAME event must stay in program order)."""
+    keys = np.asarray(keys)
+    if len(keys) < 2 or len(np.unique(keys[keys != 0])) == int((keys != 0).sum()):
+        return [(0, len(keys))]
+    out, seen, start = [], set(), 0
+    for i, k in enumerate(keys.tolist()):
+        if k and k in seen:
+            out.append((start, i)); start, seen = i, set()
+        if k:
+            seen.add(k)
+    out.append((start, len(keys)))
+    return out
