@@ -916,7 +916,7 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); return OCRGPU_EHIP; } } while (0)
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
-struct Snapshot { EdtLine *edt; EvtRec *evt; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_fired_entries; bool valid; };
+struct Snapshot { EdtLine *edt; EvtRec *evt; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries; bool valid; };
 
 struct ocrgpu_engine {
     int device; hipStream_t stream; ocrgpu_config_t cfg; Dev d;
@@ -1446,7 +1446,7 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     s.n_fired_entries = e->pinned_done[12];
     HIPCHK(hipMalloc((void **)&s.fired, 4 * (size_t)s.n_fired_entries + 16));
     HIPCHK(hipMalloc((void **)&s.ctrl, sizeof(Ctrl)));
-    s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt;
+    s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt; s.n_db = e->n_db;
     HIPCHK(hipMemcpyAsync(s.edt, d.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(s.evt, d.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(s.fired, d.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
@@ -1458,6 +1458,8 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     Dev &d = e->d; Snapshot &s = e->snap;
     if (!s.valid) FAIL(OCRGPU_EINVAL, "no snapshot taken");
     if (s.n_edt != e->n_edt || s.n_evt != e->n_evt) FAIL(OCRGPU_EINVAL, "objects were created after the snapshot");
+    e->n_db = s.n_db; // proxy datablocks cloned from other partitions since the snapshot are dropped
+    if (e->d.send_cnt) k_exchange_reset<<<1, 1024, 0, e->stream>>>(e->d);
     HIPCHK(hipMemcpyAsync(d.edt, s.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.evt, s.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(d.fired, s.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));

@@ -299,28 +299,33 @@ def resolve_lockstep(parts):
 
 
 def exchange_records(dist, send, counts, device):
-    """all-to-all-v of 32-byte records: ``send[dst, :counts[dst]]`` goes to rank dst. Returns (recv tensor, n)."""
+    """all-to-all-v of 32-byte records: ``send[dst, :counts[dst]]`` goes to rank dst. Returns (recv tensor, n).
+    With the "nccl" (= RCCL) backend everything stays on the GPU; with "gloo" (CPU tests, or several ranks sharing
+    one GPU) the records are staged through host memory."""
     import torch
     W = dist.get_world_size()
-    cnt_out = torch.as_tensor(np.asarray(counts, dtype=np.int64), device=device)
+    via_cpu = dist.get_backend() == "gloo"
+    cdev = "cpu" if via_cpu else device
+    cnt_out = torch.as_tensor(np.asarray(counts, dtype=np.int64)).to(cdev)
     cnt_in = torch.empty_like(cnt_out)
     dist.all_to_all_single(cnt_in, cnt_out)
     cin = cnt_in.cpu().numpy()
-    sendbuf = torch.cat([send[d, :int(counts[d])] for d in range(W)]) if int(np.sum(counts)) else send[0, :0]
-    recv = torch.empty((int(cin.sum()), REC_BYTES), dtype=torch.uint8, device=device)
-    dist.all_to_all_single(recv, sendbuf.contiguous(), output_split_sizes=[int(x) for x in cin],
+    pieces = [send[d, :int(counts[d])] for d in range(W) if int(counts[d])]
+    sendbuf = (torch.cat(pieces) if pieces else send[0, :0]).contiguous().to(cdev)
+    recv = torch.empty((int(cin.sum()), REC_BYTES), dtype=torch.uint8, device=cdev)
+    dist.all_to_all_single(recv, sendbuf, output_split_sizes=[int(x) for x in cin],
                            input_split_sizes=[int(x) for x in counts])
-    return recv, int(cin.sum())
+    return recv.to(device), int(cin.sum())
 
 
-def distributed_exchange(part: Partition, dist):
+def distributed_exchange(part, dist):
     """Rounds of [count all-reduce, all-to-all-v, apply, drain] until no record is in flight on any rank."""
     import torch
     dev = part.send.device
     part.drain()
     while True:
         counts = part.outgoing()
-        tot = torch.tensor([int(counts.sum())], device=dev, dtype=torch.int64)
+        tot = torch.tensor([int(counts.sum())], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.int64)
         dist.all_reduce(tot)
         if int(tot.item()) == 0:
             return
@@ -331,7 +336,7 @@ def distributed_exchange(part: Partition, dist):
         part.drain()
 
 
-def resolve_distributed(part: Partition, dist):
+def resolve_distributed(part, dist):
     """One process per GPU (torch.distributed, backend "nccl" == RCCL): deliver the main program's remote
     satisfies, then per level one FIRE step followed by rounds of [counts all-to-all + record all-to-all + apply +
     drain] until no record is in flight anywhere; one all-reduce per level decides whether anybody can still fire."""
@@ -342,7 +347,7 @@ def resolve_distributed(part: Partition, dist):
         distributed_exchange(part, dist)
 
     def anybody_ready():
-        flag = torch.tensor([1 if part.eng.step(0)[0] else 0], device=dev, dtype=torch.int64)
+        flag = torch.tensor([1 if part.eng.step(0)[0] else 0], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.int64)
         dist.all_reduce(flag)
         return int(flag.item()) != 0
 
