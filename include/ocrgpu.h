@@ -145,7 +145,8 @@ int ocrgpu_resolve(ocrgpu_engine_t *e, uint64_t max_levels, ocrgpu_stats_t *stat
  * when nothing is ready here still count one (empty) level, so partitions stepping in lockstep keep the same
  * level numbering.  *has_ready_out = 1 when EDTs are waiting to fire; *pending_records_out = queued satisfies. */
 #define OCRGPU_STEP_FORCE_LEVEL 1u
-int ocrgpu_step(ocrgpu_engine_t *e, uint32_t fire_levels, uint32_t flags, uint64_t *has_ready_out, uint64_t *pending_records_out);
+int ocrgpu_step(ocrgpu_engine_t *e, uint32_t fire_levels, uint32_t flags, uint64_t *has_ready_out,
+                uint64_t *pending_records_out, uint32_t *send_counts_out /* host [n_locations] or NULL */);
 
 /* ---- cross-partition satisfies (replace ocrCommPlatformFcts_t.sendMessage/pollMessage for PD_MSG_DEP_SATISFY,
  *      ocr/src/inc/ocr-comm-platform.h:55-199, mpi-comm-platform.c:1055, hc-dist-policy.c:2208).  The engine fills

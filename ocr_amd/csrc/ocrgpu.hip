@@ -75,7 +75,7 @@ struct RemoteDst { u64 guid; u32 slot, flags; };
 struct alignas(128) State {
     u32 mode, level, r_begin, r_end, q_begin, q_end, done, allow_fire;
     u32 r_total, q_total;   // log positions where this launch's appends start
-    u32 n_levels, pad[21];
+    u32 n_levels, force_level, pad[20];
 };
 struct alignas(128) Cnt { u32 v; u32 pad[31]; };
 struct alignas(128) Ctrl {
@@ -398,6 +398,10 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     else if (P.allow_fire && r_total > P.r_end) {
         if (P.allow_fire != 0xFFFFFFFFu) N.allow_fire = P.allow_fire - 1; // FIRE budget (distributed stepping: 1 level)
         N.mode = MODE_FIRE; N.level = P.level + 1; N.r_begin = P.r_end; N.r_end = r_total; N.n_levels = N.level + 1;
+    } else if (P.allow_fire && P.force_level) {
+        // nothing ready here, but the partitions step in lockstep: count one EMPTY level so numbering stays aligned
+        if (P.allow_fire != 0xFFFFFFFFu) N.allow_fire = P.allow_fire - 1;
+        N.mode = MODE_FIRE; N.level = P.level + 1; N.r_begin = N.r_end = P.r_end; N.n_levels = N.level + 1;
     } else N.done = 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         c->state[K & 1] = N;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     S.r_base = r_total; S.q_base = q_total; S.cnt_r = &c->cnt_r[K % 3].v; S.cnt_q = &c->cnt_q[K % 3].v;
     u64 n_edt_sat = 0, n_evt_sat = 0, n_fired = 0;
     const u32 count = (S.mode == MODE_FIRE) ? S.r_end - S.r_begin : S.q_end - S.q_begin;
-    u32 part = (count + BLK - 1) / BLK; if (part > gridDim.x) part = gridDim.x;
+    u32 part = (count + BLK - 1) / BLK; if (part > gridDim.x) part = gridDim.x; // 0 for a forced empty level
     if (blockIdx.x >= part) return; // workgroups beyond the work leave at once
     STAMP(0);
 
@@ -549,12 +553,12 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 }
 
 // Start a run at launch index K0: seed state[(K0-1)&1] from the between-runs view (single thread).
-__global__ void k_begin(Dev d, u32 K0, u32 allow_fire) {
+__global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) {
     Ctrl *c = d.ctrl;
     State P; memset(&P, 0, sizeof P);
     P.mode = MODE_EVENTS; P.level = c->level; P.r_begin = P.r_end = c->r_end; P.q_begin = P.q_end = c->q_begin;
     P.done = 0; P.allow_fire = allow_fire; P.r_total = c->r_tail; P.q_total = c->q_tail > d.q_cap ? d.q_cap : c->q_tail;
-    P.n_levels = c->n_levels;
+    P.n_levels = c->n_levels; P.force_level = force_level;
     c->state[(K0 - 1) & 1] = P;
     c->cnt_r[(K0 - 1) % 3].v = 0; c->cnt_q[(K0 - 1) % 3].v = 0;
     c->cnt_r[K0 % 3].v = 0; c->cnt_q[K0 % 3].v = 0;
@@ -1071,7 +1075,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     // ctrl.level starts at -1 (main-program satisfies are "level -1")
     Ctrl h; memset(&h, 0, sizeof h); h.level = 0xFFFFFFFFu; h.state[0].done = h.state[1].done = 1;
     if (hipMemcpyAsync(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice, e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "ctrl init failed"); }
-    if (hipHostMalloc((void **)&e->pinned_done, 64) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
+    if (hipHostMalloc((void **)&e->pinned_done, 256 + 128 * 1024) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
     if (cfg->flags & OCRGPU_F_TIMING) { if (hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess) e->have_events = true; }
     if (hipStreamSynchronize(e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "init sync failed"); }
 #undef TRY
@@ -1134,15 +1138,18 @@ static int seal(ocrgpu_engine *e) {
 }
 
 // ---- drain: run k_step launches until the device says done ---------------------------------------------
-static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool timing) {
+// Launch k_step ahead of the device until it reports `done`.  Every poll brings back the whole phase state and
+// (when partitions are configured) the per-destination send counters in ONE synchronisation: pinned[0..31] = State,
+// pinned[32 + 32*loc] = records queued for partition loc.
+static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool timing, u32 force_level = 0, u32 first_batch = 0) {
     Dev &d = e->d;
     int r = seal(e); if (r) return r;
     if (e->launch_index > 0xFFFF0000u) e->launch_index = 8; // keep K-1 and K%3 arithmetic away from the wrap
     u32 K = e->launch_index + 1;
-    k_begin<<<1, 1, 0, e->stream>>>(d, K, allow_fire);
+    k_begin<<<1, 1, 0, e->stream>>>(d, K, allow_fire, force_level);
     const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
     const u32 grid = e->step_grid > MAX_GRID ? MAX_GRID : (e->step_grid ? e->step_grid : 256u);
-    u32 batch = allow_fire ? 8 : 2;
+    u32 batch = first_batch ? first_batch : (allow_fire ? 8 : 2);
     u64 launched = 0;
     if (timing && e->have_events) HIPCHK(hipEventRecord(e->ev0, e->stream));
     for (;;) {
@@ -1150,9 +1157,10 @@ static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool ti
             if (nanny) k_step<true><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false><<<grid, BLK, 0, e->stream>>>(d, K);
         }
         launched += batch;
-        HIPCHK(hipMemcpyAsync(e->pinned_done, &d.ctrl->state[(K - 1) & 1].done, 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(e->pinned_done, &d.ctrl->state[(K - 1) & 1], sizeof(State), hipMemcpyDeviceToHost, e->stream));
+        if (d.send_cnt) HIPCHK(hipMemcpyAsync(e->pinned_done + 32, d.send_cnt, 128 * (size_t)d.n_loc, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
-        if (*e->pinned_done) break;
+        if (((State *)e->pinned_done)->done) break;
         if (launched >= max_launches) break;
         if (batch < 64) batch *= 2;
     }
@@ -1170,10 +1178,10 @@ static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool ti
 static int drain_events(ocrgpu_engine *e) {
     if (e->defer_drain) return 0; // distributed stepping: the driver calls ocrgpu_step
     // q_begin and q_tail sit in different cache lines of Ctrl: two 4-byte reads, one sync
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 8, &e->d.ctrl->q_begin, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 9, &e->d.ctrl->q_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33008, &e->d.ctrl->q_begin, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33009, &e->d.ctrl->q_tail, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->pinned_done[9] <= e->pinned_done[8]) return 0; // nothing queued: registrations only
+    if (e->pinned_done[33009] <= e->pinned_done[33008]) return 0; // nothing queued: registrations only
     return run_steps(e, 0u, ~0ull, false);
 }
 
@@ -1270,9 +1278,9 @@ extern "C" int ocrgpu_edt_create(ocrgpu_engine_t *e, u64 n, const u32 *depc, con
     u32 *dovf = (u32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += rup(4 * n);
     k_ovf_counts<<<nblk(n), 256, 0, e->stream>>>(n, dd, dovf);
     if ((r = scan_u32(e, dovf, dsb, n, (u32)e->n_slots, dtot))) return r;
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 4, dtot, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33000, dtot, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    u64 add = e->pinned_done[4] - (u32)e->n_slots; // the scan was seeded with the slots already in use
+    u64 add = e->pinned_done[33000] - (u32)e->n_slots; // the scan was seeded with the slots already in use
     if (e->n_slots + add > e->d.max_slots) FAIL(OCRGPU_ENOMEM, "max_slots=%llu exhausted", (unsigned long long)e->d.max_slots);
     k_edt_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dd, db, dp, dsb, e->n_edt, e->counter, dg, doe, dod);
     e->n_edt += (u32)n; e->n_slots += add; e->counter += 3 * n;
@@ -1363,27 +1371,20 @@ extern "C" int ocrgpu_resolve(ocrgpu_engine_t *e, u64 max_levels, ocrgpu_stats_t
     if (stats_out) { r = fetch_stats(e, stats_out); if (r) return r; e->last = *stats_out; }
     return 0;
 }
-extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *has_ready_out, u64 *pending_records_out) {
+extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *has_ready_out, u64 *pending_records_out,
+                           u32 *send_counts_out) {
     ENTER(e);
-    Dev &d = e->d;
-    // anything to fire?  (log entries beyond the last fired level; may be holes only, which is harmless)
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 8, &d.ctrl->r_end, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 9, &d.ctrl->r_tail, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    bool ready_before = e->pinned_done[9] > e->pinned_done[8];
-    if (fire_levels && !ready_before && (flags & OCRGPU_STEP_FORCE_LEVEL)) {
-        int r0 = run_steps(e, 0u, ~0ull, false); if (r0) return r0; // close pending event chains first
-        k_bump_level<<<1, 1, 0, e->stream>>>(d);
-    } else {
-        int r = run_steps(e, fire_levels, ~0ull, true); if (r) return r;
+    // one run: close pending satisfies, fire at most `fire_levels` levels (an empty one if forced), close again;
+    // 3 launches cover the common single-level case (FIRE, the no-op that notices quiescence, one spare)
+    int r = run_steps(e, fire_levels, ~0ull, true, (flags & OCRGPU_STEP_FORCE_LEVEL) ? 1u : 0u, fire_levels == 1 ? 3u : 2u);
+    if (r) return r;
+    const State *S = (const State *)e->pinned_done; // the poll that saw `done` brought the final state and counters
+    if (has_ready_out) *has_ready_out = S->r_total > S->r_end ? 1 : 0;
+    if (pending_records_out) *pending_records_out = S->q_total > S->q_end ? S->q_total - S->q_end : 0;
+    if (send_counts_out) {
+        if (!e->d.send_cnt) FAIL(OCRGPU_EINVAL, "exchange not configured");
+        for (u32 l = 0; l < e->d.n_loc; ++l) { u32 c = e->pinned_done[32 + 32 * l]; send_counts_out[l] = c > e->d.send_cap ? e->d.send_cap : c; }
     }
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 8, &d.ctrl->r_end, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 9, &d.ctrl->r_tail, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 10, &d.ctrl->q_begin, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 11, &d.ctrl->q_tail, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (has_ready_out) *has_ready_out = e->pinned_done[9] > e->pinned_done[8] ? 1 : 0;
-    if (pending_records_out) *pending_records_out = e->pinned_done[11] > e->pinned_done[10] ? e->pinned_done[11] - e->pinned_done[10] : 0;
     return 0;
 }
 
@@ -1441,9 +1442,9 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     if (s.valid) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.fired); (void)hipFree(s.ctrl); s.valid = false; }
     HIPCHK(hipMalloc((void **)&s.edt, sizeof(EdtLine) * (size_t)e->n_edt + 64));
     HIPCHK(hipMalloc((void **)&s.evt, sizeof(EvtRec) * (size_t)e->n_evt + 64));
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 12, &d.ctrl->r_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33012, &d.ctrl->r_tail, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    s.n_fired_entries = e->pinned_done[12];
+    s.n_fired_entries = e->pinned_done[33012];
     HIPCHK(hipMalloc((void **)&s.fired, 4 * (size_t)s.n_fired_entries + 16));
     HIPCHK(hipMalloc((void **)&s.ctrl, sizeof(Ctrl)));
     s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt; s.n_db = e->n_db;

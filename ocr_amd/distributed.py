@@ -252,26 +252,46 @@ class Partition:
             dbv[np.asarray(self.my_dbs)] = eng.read_dbs(0, 0, len(self.my_dbs))
 
 
-def _lockstep_exchange(parts):
+# ---- the per-level protocol ------------------------------------------------------------------------------------
+# One engine call per round (`Engine.step`: close pending satisfies, optionally fire ONE level, close again; its
+# single synchronisation also brings back the per-destination send counters and the "EDTs are ready" flag), then
+#   1. one small all-gather of [counts to every rank..., ready flag]  -> every rank knows the whole W x W matrix,
+#   2. if any record is in flight: one all-to-all-v of the 32-byte records, apply, and another round without firing;
+#   3. else if anybody is ready: next level; else the resolve is over.
+# Levels stay exact: nobody fires level L+1 before every satisfy of level L (event chains across partitions
+# included) has been delivered and closed.
+
+def _lockstep_round(parts, fire):
+    W = len(parts)
+    M = np.zeros((W, W + 1), dtype=np.int64)
+    for r, p in enumerate(parts):
+        ready, _, counts = p.eng.step(1 if fire else 0, force_level=bool(fire), want_counts=True)
+        M[r, :W], M[r, W] = counts, int(ready)
+    return M
+
+
+def _lockstep_settle(parts, M=None):
+    """Exchange until no record is in flight (device-to-device copies stand in for the all-to-all)."""
     torch = parts[0].torch
     W = len(parts)
-    if True:
+    if M is None:
+        M = _lockstep_round(parts, False)
+    while M[:, :W].sum() > 0:
+        inbox = []
+        for dst in range(W):
+            chunks = [parts[src].send[dst, :int(M[src, dst])] for src in range(W) if M[src, dst]]
+            inbox.append(torch.cat(chunks).contiguous() if chunks else None)
         for p in parts:
-            p.drain()                                                 # close local event chains first
-        while True:
-            counts = np.stack([p.outgoing() for p in parts])         # counts[src][dst]
-            if counts.sum() == 0:
-                return
-            inbox = []
-            for dst in range(W):
-                chunks = [parts[src].send[dst, :int(counts[src][dst])] for src in range(W) if counts[src][dst]]
-                inbox.append(torch.cat(chunks).contiguous() if chunks else None)
-            for p in parts:
-                p.eng.exchange_reset()
-            for dst, p in enumerate(parts):
-                if inbox[dst] is not None:
-                    p.eng.exchange_apply(inbox[dst].data_ptr(), inbox[dst].shape[0])
-                p.drain()
+            p.eng.exchange_reset()
+        for dst, p in enumerate(parts):
+            if inbox[dst] is not None:
+                p.eng.exchange_apply(inbox[dst].data_ptr(), inbox[dst].shape[0])
+        M = _lockstep_round(parts, False)
+    return M
+
+
+def _lockstep_exchange(parts):
+    _lockstep_settle(parts)
 
 
 def build_lockstep(parts):
@@ -282,81 +302,81 @@ def build_lockstep(parts):
         assert all(alive) or not any(alive), "partitions walked different batch sequences"
         if not any(alive):
             return parts
-        _lockstep_exchange(parts)
+        _lockstep_settle(parts)
 
 
 def resolve_lockstep(parts):
     """Drive several partitions that live in ONE process (tests: all on one GPU).  Same protocol as
-    :func:`resolve_distributed`, with device-to-device copies standing in for the all-to-all."""
+    :func:`resolve_distributed`."""
+    W = len(parts)
     levels = 0
-    _lockstep_exchange(parts)
-    while any(p.eng.step(0)[0] for p in parts):
-        for p in parts:
-            p.fire_one_level()
+    M = _lockstep_settle(parts)
+    while M[:, W].sum() > 0:
+        M = _lockstep_settle(parts, _lockstep_round(parts, True))
         levels += 1
-        _lockstep_exchange(parts)
     return levels
 
 
 def exchange_records(dist, send, counts, device):
-    """all-to-all-v of 32-byte records: ``send[dst, :counts[dst]]`` goes to rank dst. Returns (recv tensor, n).
-    With the "nccl" (= RCCL) backend everything stays on the GPU; with "gloo" (CPU tests, or several ranks sharing
-    one GPU) the records are staged through host memory."""
+    """all-to-all-v of 32-byte records when the receive counts are NOT known yet: ``send[dst, :counts[dst]]`` goes
+    to rank dst.  Returns (recv tensor, n)."""
     import torch
     W = dist.get_world_size()
-    via_cpu = dist.get_backend() == "gloo"
-    cdev = "cpu" if via_cpu else device
+    cdev = "cpu" if dist.get_backend() == "gloo" else device
     cnt_out = torch.as_tensor(np.asarray(counts, dtype=np.int64)).to(cdev)
     cnt_in = torch.empty_like(cnt_out)
     dist.all_to_all_single(cnt_in, cnt_out)
     cin = cnt_in.cpu().numpy()
-    pieces = [send[d, :int(counts[d])] for d in range(W) if int(counts[d])]
-    sendbuf = (torch.cat(pieces) if pieces else send[0, :0]).contiguous().to(cdev)
-    recv = torch.empty((int(cin.sum()), REC_BYTES), dtype=torch.uint8, device=cdev)
-    dist.all_to_all_single(recv, sendbuf, output_split_sizes=[int(x) for x in cin],
-                           input_split_sizes=[int(x) for x in counts])
-    return recv.to(device), int(cin.sum())
+    return exchange_payload(dist, send, counts, cin, device), int(cin.sum())
 
 
-def distributed_exchange(part, dist):
-    """Rounds of [count all-reduce, all-to-all-v, apply, drain] until no record is in flight on any rank."""
+def exchange_payload(dist, send, counts_out, counts_in, device):
+    """The record all-to-all-v with known splits.  With the "nccl" (= RCCL) backend everything stays on the GPU; with
+    "gloo" (CPU tests, or several ranks sharing one GPU) the records are staged through host memory."""
     import torch
-    dev = part.send.device
-    part.drain()
-    while True:
-        counts = part.outgoing()
-        tot = torch.tensor([int(counts.sum())], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.int64)
-        dist.all_reduce(tot)
-        if int(tot.item()) == 0:
-            return
-        recv, n = exchange_records(dist, part.send, counts, dev)
+    W = dist.get_world_size()
+    cdev = "cpu" if dist.get_backend() == "gloo" else device
+    pieces = [send[d, :int(counts_out[d])] for d in range(W) if int(counts_out[d])]
+    sendbuf = (torch.cat(pieces) if pieces else send[0, :0]).contiguous().to(cdev)
+    recv = torch.empty((int(np.sum(counts_in)), REC_BYTES), dtype=torch.uint8, device=cdev)
+    dist.all_to_all_single(recv, sendbuf, output_split_sizes=[int(x) for x in counts_in],
+                           input_split_sizes=[int(x) for x in counts_out])
+    return recv.to(device)
+
+
+def _dist_round(part, dist, fire):
+    import torch
+    W, rank = dist.get_world_size(), dist.get_rank()
+    cdev = "cpu" if dist.get_backend() == "gloo" else part.send.device
+    ready, _, counts = part.eng.step(1 if fire else 0, force_level=bool(fire), want_counts=True)
+    vec = torch.tensor([int(c) for c in counts] + [int(ready)], dtype=torch.int64, device=cdev)
+    rows = [torch.empty_like(vec) for _ in range(W)]
+    dist.all_gather(rows, vec)
+    return torch.stack(rows).cpu().numpy()
+
+
+def distributed_exchange(part, dist, M=None):
+    """Rounds of [status all-gather, record all-to-all-v, apply, close] until no record is in flight on any rank."""
+    W, rank = dist.get_world_size(), dist.get_rank()
+    if M is None:
+        M = _dist_round(part, dist, False)
+    while M[:, :W].sum() > 0:
+        recv = exchange_payload(dist, part.send, M[rank, :W], M[:, rank], part.send.device)
         part.eng.exchange_reset()
-        if n:
-            part.eng.exchange_apply(recv.data_ptr(), n)
-        part.drain()
+        if recv.shape[0]:
+            part.eng.exchange_apply(recv.data_ptr(), recv.shape[0])
+        M = _dist_round(part, dist, False)
+    return M
 
 
 def resolve_distributed(part, dist):
-    """One process per GPU (torch.distributed, backend "nccl" == RCCL): deliver the main program's remote
-    satisfies, then per level one FIRE step followed by rounds of [counts all-to-all + record all-to-all + apply +
-    drain] until no record is in flight anywhere; one all-reduce per level decides whether anybody can still fire."""
-    import torch
-    dev = part.send.device
-
-    def exchange_rounds():
-        distributed_exchange(part, dist)
-
-    def anybody_ready():
-        flag = torch.tensor([1 if part.eng.step(0)[0] else 0], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.int64)
-        dist.all_reduce(flag)
-        return int(flag.item()) != 0
-
+    """One process per GPU (torch.distributed, backend "nccl" == RCCL).  Returns the number of levels fired."""
+    W = dist.get_world_size()
     levels = 0
-    exchange_rounds()
-    while anybody_ready():
-        part.fire_one_level()
+    M = distributed_exchange(part, dist)
+    while M[:, W].sum() > 0:
+        M = distributed_exchange(part, dist, _dist_round(part, dist, True))
         levels += 1
-        exchange_rounds()
     return levels
 
 
