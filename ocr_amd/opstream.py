@@ -393,3 +393,181 @@ def split_conflicts(keys):
             seen.add(k)
     out.append((start, len(keys)))
     return out
+
+
+def _finish_stream(N, depc, src_ref, dst_idx, slot, mode, extra_main=(), evt_extra=(), name="", meta=None,
+                   bodies=None, db_init=None, start_targets=None):
+    """Common tail of the bulk generators: EDTs 0..N-1 (HASH bodies, ONCE output events) with dependences
+    (src_ref[i] -> EDT dst_idx[i], slot[i], mode[i]); EDTs in ``start_targets`` take the start event on their LAST
+    pre-slot; output events nobody consumes DECR the sink latch; sink EDT = N.  Events: 0 = start (ONCE), 1 = sink
+    latch, then ``evt_extra``."""
+    consumed = np.zeros(N, dtype=bool)
+    cls = ref_cls(np.asarray(src_ref, dtype=np.uint64))
+    oe = cls == REF_OUTEVT
+    consumed[ref_idx(np.asarray(src_ref, dtype=np.uint64))[oe].astype(np.int64)] = True
+    for ops_arr in extra_main:
+        m = (ops_arr["op"] == OP_ADD_DEP) & (ref_cls(ops_arr["a"]) == REF_OUTEVT)
+        consumed[ref_idx(ops_arr["a"][m]).astype(np.int64)] = True
+    leaves = np.nonzero(~consumed)[0]
+    edt = np.zeros(N + 1, dtype=EDT_DT)
+    edt["depc"][:N] = depc
+    edt["body"][:N] = (BODY_HASH | BODY_F_OUTEVT) if bodies is None else bodies
+    edt["depc"][N] = 1
+    edt["body"][N] = BODY_NOP | BODY_F_SINK
+    evt = np.zeros(2 + len(evt_extra), dtype=EVT_DT)
+    evt["kind"][:2] = [EVT_ONCE, EVT_LATCH]
+    evt["arg"][1] = len(leaves)
+    for i, (k, a) in enumerate(evt_extra):
+        evt[2 + i] = (k, a)
+    db_init = np.zeros(0, np.uint64) if db_init is None else np.asarray(db_init, np.uint64)
+    st = np.asarray(start_targets if start_targets is not None else [], dtype=np.int64)
+    parts = [make_ops(OP_EVT_CREATE, np.arange(len(evt))), make_ops(OP_DB_CREATE, np.arange(len(db_init))),
+             make_ops(OP_EDT_CREATE, np.arange(N + 1)),
+             make_ops(OP_ADD_DEP, src_ref, b=ref(REF_EDT, np.asarray(dst_idx, dtype=np.int64)), slot=slot, mode=mode)]
+    parts += list(extra_main)
+    parts += [make_ops(OP_ADD_DEP, np.full(len(st), ref(REF_EVT, 0), dtype=np.uint64), b=ref(REF_EDT, st),
+                       slot=(np.asarray(depc)[st] - 1).astype(np.uint32), mode=MODE_NULL),
+              make_ops(OP_ADD_DEP, ref(REF_OUTEVT, leaves), b=ref(REF_EVT, 1), slot=LATCH_DECR, mode=MODE_NULL),
+              make_ops(OP_ADD_DEP, [ref(REF_EVT, 1)], b=ref(REF_EDT, N), slot=0, mode=MODE_NULL),
+              make_ops(OP_SATISFY, [ref(REF_EVT, 0)], b=0, slot=0)]
+    main = np.concatenate([p for p in parts if len(p)])
+    m = dict(meta or {})
+    m.update(n_leaves=len(leaves), n_satisfactions=int(np.asarray(depc, dtype=np.int64).sum()) + 1 + len(leaves))
+    return OpStream(edt, evt, db_init, main, np.zeros(0, dtype=OP_DT), N, name=name, meta=m)
+
+
+def cholesky_dag(T: int, name=None) -> OpStream:
+    """BASELINE config 3: right-looking tiled Cholesky, T tiles per side, datablock-carried
+    dependences.  potrf(k) <- syrk(k-1,k); trsm(k,i) <- potrf(k), gemm(k-1,i,k); syrk(k,i) <- trsm(k,i), syrk(k-1,i);
+    gemm(k,i,j) <- trsm(k,i), trsm(k,j), gemm(k-1,i,j)   (i > j > k).  At k = 0 the "previous update" is the initial
+    tile, an explicit DB added with ocrAddDependence(db, edt, slot).  T + T(T-1) + T(T-1)(T-2)/6 EDTs, fan-in <= 3."""
+    k_, i_ = np.triu_indices(T, 1)                       # pairs k < i
+    nP, nTr = T, len(k_)
+    gi, gj, gk = [], [], []
+    for k in range(T):
+        jj, ii = np.triu_indices(T - k - 1, 1)            # j < i within (k, T)
+        gi.append(ii + k + 1); gj.append(jj + k + 1); gk.append(np.full(len(ii), k))
+    gi, gj, gk = (np.concatenate(x).astype(np.int64) if len(x) else np.zeros(0, np.int64) for x in (gi, gj, gk))
+    nG = len(gi)
+    P0, TR0, SY0, G0 = 0, nP, nP + nTr, nP + 2 * nTr
+    N = nP + 2 * nTr + nG
+    pair_id = -np.ones((T, T), dtype=np.int64)
+    pair_id[k_, i_] = np.arange(nTr)
+
+    def potrf(k): return P0 + k
+    def trsm(k, i): return TR0 + pair_id[k, i]
+    def syrk(k, i): return SY0 + pair_id[k, i]
+    gid = {}
+    # gemm id lookup through a dense 3-index table is too big for T=256 (16.7M) -> still fine as int32
+    gtab = -np.ones((T, T, T), dtype=np.int32) if T <= 256 else None
+    gtab[gk, gi, gj] = np.arange(nG, dtype=np.int32)
+    def gemm(k, i, j): return G0 + gtab[k, i, j].astype(np.int64)
+    tile_db = lambda i, j: i * T + j                      # explicit DB index of the initial tile (i, j)
+    depc = np.zeros(N, dtype=np.uint32)
+    depc[P0:P0 + nP] = 1; depc[TR0:TR0 + nTr] = 2; depc[SY0:SY0 + nTr] = 2; depc[G0:] = 3
+    S, D, SL = [], [], []
+    def add(src, dst, slot): S.append(np.asarray(src, np.uint64)); D.append(np.asarray(dst, np.int64)); SL.append(np.full(len(np.atleast_1d(dst)), slot, np.uint32))
+    ks = np.arange(T)
+    # potrf(k): slot 0 <- syrk(k-1,k) | A(k,k)
+    add(ref(REF_DB, tile_db(ks[:1], ks[:1])), potrf(ks[:1]), 0)
+    if T > 1:
+        add(ref(REF_OUTEVT, syrk(ks[1:] - 1, ks[1:])), potrf(ks[1:]), 0)
+    # trsm(k,i): slot 0 <- potrf(k); slot 1 <- gemm(k-1,i,k) | A(i,k)
+    add(ref(REF_OUTEVT, potrf(k_)), trsm(k_, i_), 0)
+    m0 = k_ == 0
+    add(ref(REF_DB, tile_db(i_[m0], k_[m0])), trsm(k_[m0], i_[m0]), 1)
+    add(ref(REF_OUTEVT, gemm(k_[~m0] - 1, i_[~m0], k_[~m0])), trsm(k_[~m0], i_[~m0]), 1)
+    # syrk(k,i): slot 0 <- trsm(k,i); slot 1 <- syrk(k-1,i) | A(i,i)
+    add(ref(REF_OUTEVT, trsm(k_, i_)), syrk(k_, i_), 0)
+    add(ref(REF_DB, tile_db(i_[m0], i_[m0])), syrk(k_[m0], i_[m0]), 1)
+    add(ref(REF_OUTEVT, syrk(k_[~m0] - 1, i_[~m0])), syrk(k_[~m0], i_[~m0]), 1)
+    # gemm(k,i,j): slot 0 <- trsm(k,i); slot 1 <- trsm(k,j); slot 2 <- gemm(k-1,i,j) | A(i,j)
+    if nG:
+        g_all = G0 + np.arange(nG)
+        add(ref(REF_OUTEVT, trsm(gk, gi)), g_all, 0)
+        add(ref(REF_OUTEVT, trsm(gk, gj)), g_all, 1)
+        g0 = gk == 0
+        add(ref(REF_DB, tile_db(gi[g0], gj[g0])), g_all[g0], 2)
+        add(ref(REF_OUTEVT, gemm(gk[~g0] - 1, gi[~g0], gj[~g0])), g_all[~g0], 2)
+    src, dst, slot = np.concatenate(S), np.concatenate(D), np.concatenate(SL)
+    # DB sources are immediate satisfies: the start event gates every EDT that has ONLY DB inputs? none here need it:
+    # potrf(0) has only a DB input and would fire during construction, so give the k=0 layer an extra start slot.
+    first = np.r_[potrf(np.array([0])), trsm(k_[m0], i_[m0]), syrk(k_[m0], i_[m0]), (G0 + np.nonzero(gk == 0)[0]) if nG else np.zeros(0, np.int64)]
+    depc[first] += 1
+    db_init = splitmix64(SEED_BASE + 3, T * T)
+    mode = np.where(ref_cls(src) == REF_DB, MODE_RO, MODE_RW).astype(np.uint8)
+    return _finish_stream(N, depc, src, dst, slot, mode, name=name or f"cholesky_T{T}", db_init=db_init,
+                          start_targets=first, meta=dict(kind="cholesky", T=T))
+
+
+def stencil_dag(G: int, steps: int, name=None) -> OpStream:
+    """BASELINE config 4: 2D 5-point stencil on G x G tiles for `steps` steps.  EDT(t,i,j) depends
+    on (t-1,i,j) [slot 0] and its N,S,W,E neighbours at t-1 [slots 1..]; every dependence is the ONCE output event of
+    the producer carrying its datablock (the "halo satisfy")."""
+    n_tile = G * G
+    N = n_tile * steps
+    ii, jj = np.divmod(np.arange(n_tile, dtype=np.int64), G)
+    nb = [(ii, jj)]
+    for di, dj in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+        ni, nj = ii + di, jj + dj
+        ok = (ni >= 0) & (ni < G) & (nj >= 0) & (nj < G)
+        nb.append((np.where(ok, ni, -1), nj))
+    valid = np.stack([n[0] >= 0 for n in nb], axis=1)             # [tile, 5]
+    nbr = np.stack([np.where(n[0] >= 0, n[0] * G + n[1], 0) for n in nb], axis=1)
+    slot_of = np.cumsum(valid, axis=1) - 1                         # compact slots per tile
+    fanin = valid.sum(axis=1).astype(np.uint32)
+    depc = np.empty(N, dtype=np.uint32)
+    depc[:n_tile] = 1                                              # step 0: start event only
+    depc[n_tile:] = np.tile(fanin, steps - 1)
+    t_idx, d_idx = np.nonzero(valid)
+    S, D, SL = [], [], []
+    for t in range(1, steps):
+        S.append((t - 1) * n_tile + nbr[t_idx, d_idx]); D.append(t * n_tile + t_idx); SL.append(slot_of[t_idx, d_idx])
+    src = ref(REF_OUTEVT, np.concatenate(S)) if S else np.zeros(0, np.uint64)
+    dst = np.concatenate(D) if D else np.zeros(0, np.int64)
+    slot = (np.concatenate(SL) if SL else np.zeros(0)).astype(np.uint32)
+    return _finish_stream(N, depc, src, dst, slot, MODE_RO, name=name or f"stencil_{G}x{G}x{steps}",
+                          start_targets=np.arange(n_tile), meta=dict(kind="stencil", G=G, steps=steps))
+
+
+def powerlaw_dag(n_edt: int, seed: int = SEED_BASE + 5, alpha: float = 2.1, cap: int = 1_000_000, group: int = 1024,
+                 name=None) -> OpStream:
+    """BASELINE config 5: power-law fan-out DAG with latch events.  EDT ids are a topological
+    order; EDT e has out-degree ~ Zipf(alpha) (capped) to targets drawn uniformly from (e, n); every `group`
+    consecutive EDTs check out of one LATCH (initial count = group size: the INCR-on-create half of a finish scope,
+    hc-task.c:1071-1078, done at construction), and the group latches check out of one root latch that fires the
+    sink.  EDTs without a data predecessor hang off the start event."""
+    N = n_edt
+    u = (splitmix64(seed, N).astype(np.float64) + 0.5) / 2.0 ** 64
+    deg = np.minimum(np.floor(u ** (-1.0 / (alpha - 1.0))).astype(np.int64), cap)   # P(D >= d) = d^-(alpha-1)
+    deg = np.minimum(deg, N - 1 - np.arange(N))
+    deg[deg < 0] = 0
+    E = int(deg.sum())
+    src = np.repeat(np.arange(N, dtype=np.int64), deg)
+    r = splitmix64(seed ^ 0x5EED, E)
+    span = (N - 1 - src).astype(np.uint64)
+    dst = src + 1 + (r % np.maximum(span, np.uint64(1))).astype(np.int64)
+    order = np.lexsort((src, dst))
+    src, dst = src[order], dst[order]
+    indeg = np.bincount(dst, minlength=N).astype(np.int64)
+    first_of = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(indeg, out=first_of[1:])
+    slot = (np.arange(E, dtype=np.int64) - first_of[dst]).astype(np.uint32)
+    roots = np.nonzero(indeg == 0)[0]
+    depc = indeg.astype(np.uint32)
+    depc[roots] = 1
+    n_groups = (N + group - 1) // group
+    gsize = np.bincount(np.arange(N) // group, minlength=n_groups)
+    evt_extra = [(EVT_LATCH, n_groups)] + [(EVT_LATCH, int(g)) for g in gsize]   # event 2 = root latch, 3.. = groups
+    # every EDT's output event -> its group latch (DECR); group latch -> root latch (DECR); root -> sink latch handled
+    # by making the root latch's post-slot the only "leaf": we route root latch -> event 1 (the generic sink latch)
+    extra = [make_ops(OP_ADD_DEP, ref(REF_OUTEVT, np.arange(N)), b=ref(REF_EVT, 3 + np.arange(N) // group), slot=LATCH_DECR, mode=MODE_NULL),
+             make_ops(OP_ADD_DEP, ref(REF_EVT, 3 + np.arange(n_groups)), b=np.full(n_groups, ref(REF_EVT, 2), np.uint64), slot=LATCH_DECR, mode=MODE_NULL),
+             make_ops(OP_ADD_DEP, [ref(REF_EVT, 2)], b=ref(REF_EVT, 1), slot=LATCH_DECR, mode=MODE_NULL)]
+    s = _finish_stream(N, depc, ref(REF_OUTEVT, src), dst, slot, MODE_RO, extra_main=extra, evt_extra=evt_extra,
+                       name=name or f"powerlaw_N{N}", start_targets=roots,
+                       meta=dict(kind="powerlaw", n_edges=E, n_groups=n_groups, max_outdeg=int(deg.max())))
+    # all output events are consumed by group latches -> no generic leaves; the sink latch counts the root latch only
+    s.evt["arg"][1] = 1
+    s.meta["n_satisfactions"] = int(depc.astype(np.int64).sum()) + 1 + N + n_groups + 1
+    return s

@@ -7,7 +7,8 @@ testOcrEventParam*.c, dist/testDuplicateDeps*.c) as data, so all three executors
 Every stream is well formed: its outcome does not depend on the schedule.
 """
 from ocr_amd.opstream import (BODY_FWD0, BODY_HASH, BODY_NOP, EVT_IDEM, EVT_LATCH, EVT_ONCE, EVT_STICKY,
-                              LATCH_DECR, LATCH_INCR, MODE_NULL, MODE_RO, MODE_RW, Builder, layered_dag)
+                              LATCH_DECR, LATCH_INCR, MODE_NULL, MODE_RO, MODE_RW, Builder, cholesky_dag, layered_dag,
+                              powerlaw_dag, stencil_dag)
 
 
 def chain(b, n, start):
@@ -236,4 +237,9 @@ def all_streams():
     out = [f() for f in SEMANTIC]
     out.append(layered_dag(1000, 100, name="layered_1k"))
     out.append(layered_dag(100_000, 1000, name="layered_100k"))
+    # small twins of BASELINE configs 3, 4 and 5
+    out.append(cholesky_dag(8, name="cholesky_T8"))
+    out.append(cholesky_dag(32, name="cholesky_T32"))
+    out.append(stencil_dag(16, 10, name="stencil_16x16x10"))
+    out.append(powerlaw_dag(100_000, name="powerlaw_100k"))
     return out

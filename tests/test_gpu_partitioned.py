@@ -24,7 +24,7 @@ def run_partitioned(s, world):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("name", sorted(n for n in ALL if n != "layered_100k"))
+@pytest.mark.parametrize("name", sorted(n for n in ALL if n not in ("layered_100k", "powerlaw_100k")))
 def test_semantic_streams_are_partition_invariant(name, world):
     s = ALL[name]
     res, errs = run_partitioned(s, world)
@@ -33,8 +33,9 @@ def test_semantic_streams_are_partition_invariant(name, world):
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_layered_100k_partitioned(world):
-    s = layered_dag(100_000, 1000)
+@pytest.mark.parametrize("name", ["layered_100k", "powerlaw_100k"])
+def test_large_streams_partitioned(name, world):
+    s = ALL[name]
     res, errs = run_partitioned(s, world)
     assert all(sum(e) == 0 for e in errs), errs
     assert res.diff(O.run_restatement(s)) == []
