@@ -128,8 +128,11 @@ def main():
                        "edts_fired_per_s": s.n_edt * world / (dt / args.steps), "build_s": round(build_s, 2),
                        "k_step_launches_per_resolve": launches, "parity": parity},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / step_kernel_s / 1e9, "peak": 8000.0, "unit": "GB/s",
-                         "frac": alg_bytes / step_kernel_s / 1e9 / 8000.0, "traffic": None,
+                         "frac": alg_bytes / step_kernel_s / 1e9 / 8000.0,
+                         "traffic": profiled_traffic(args),
                          "kernel": "k_step (all launches of one resolve, HIP events on the engine stream)",
+                         "launches_per_resolve": launches, "alg_bytes_per_launch": alg_bytes / launches,
+                         "us_per_launch": step_kernel_s / launches * 1e6,
                          "alg_bytes_per_resolve": alg_bytes, "kernel_s_per_resolve": step_kernel_s},
         }
         if not args.no_cpu_baseline:
@@ -218,6 +221,27 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
         print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def profiled_traffic(args, tag="r01b_config2"):
+    """HBM bytes per k_step launch from the committed PMC passes (profiles/<tag>_pmc_summary.txt: FETCH_SIZE and
+    WRITE_SIZE in KB, separate rocprofv3 --pmc runs of this same workload).  Counters cannot be read inside this
+    process, so the figure is the profiled one; None for any other workload shape."""
+    if args.n_edt != 10_000_000 or args.width != 10_000:
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tag + "_pmc_summary.txt")
+    kb = {}
+    try:
+        for line in open(path):
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                if "k_step" in line and ctr + " sum=" in line:
+                    kb[ctr] = float(line.split("per dispatch ")[1].rstrip(")\n"))
+    except OSError:
+        return None
+    if len(kb) != 2:
+        return None
+    # scattered <=64-B requests: raw values (the guide's x2 correction is for 16-B-per-lane coalesced streams only)
+    return (kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
 
 
 def cpu_baseline(args):

@@ -1,15 +1,16 @@
 // libocrgpu -- MI355X (gfx950, CDNA4) dependence-resolution engine behind include/ocrgpu.h.
 //
 // What runs where (DESIGN.md has the long form):
-//   HBM-resident SoA state       : EDT pending-slot counters, pre-slot payload words, event state
-//                                  words, CSR waiter rows, the fired-EDT log, the satisfy-record log
-//                                  and the GUID open-addressing table.
+//   HBM-resident state           : one 64-B line per EDT (pending counter, inline pre-slot words, its ONCE
+//                                  output event), 16-B event records, CSR waiter rows, the fired-EDT log,
+//                                  the satisfy-record log and the GUID open-addressing table.
 //   k_step (the hot kernel)      : one launch = one phase.  FIRE: pop a level of ready EDTs from the
 //                                  fired log, run their bodies, satisfy their output events in-block
 //                                  and fan the satisfies out edge-balanced over the whole workgroup;
 //                                  EVENTS: the same fan-out for satisfy records queued by chained
-//                                  events / API calls.  The last workgroup to finish decides the next
-//                                  phase on the device, so the host launches ahead and only polls `done`.
+//                                  events / API calls.  Every workgroup of launch K derives the phase
+//                                  from launch K-1's replicated state + append counters (no ticket, no
+//                                  grid barrier), so the host launches ahead and only polls `done`.
 //   wave64 idioms                : ballot + mbcnt prefix for ready-set / record compaction (one global
 //                                  atomic per wave), readfirstlane grouping for latch counters (one
 //                                  atomic per distinct latch per wave), LDS scan for edge balancing.
@@ -794,12 +795,6 @@ __global__ void k_exchange_apply(Dev d, u64 n, const SendRec *recs, u32 proxy_ba
 }
 __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
 __global__ void k_exchange_counts(Dev d, u32 *out) { if (threadIdx.x < d.n_loc) { u32 c = d.send_cnt[threadIdx.x * 32]; out[threadIdx.x] = c > d.send_cap ? d.send_cap : c; } }
-// an empty level on this partition (others may have fired): keep the global level numbering aligned
-__global__ void k_bump_level(Dev d) {
-    Ctrl *c = d.ctrl;
-    u32 nl = c->level + 1; c->level = nl; c->n_levels = nl + 1;
-    if (nl < d.max_levels) { d.level_start[nl] = c->r_end; d.level_start[nl + 1] = c->r_end; } else c->err[ERR_LEVEL_OVERFLOW]++;
-}
 
 // ---- CSR (re)build from the registration log: count -> scan -> fill --------------------------------
 __global__ void k_csr_clear(Dev d, u32 n_evt_total) {

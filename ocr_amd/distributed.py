@@ -227,16 +227,6 @@ class Partition:
         sc["payload_kind"], sc["payload"] = pk, pay
         self.eng.edt_set_scripts(self.edt_guid[has], np.asarray(begins, np.uint32), np.asarray(lens, np.uint32), sc)
 
-    # -- the per-level protocol --
-    def fire_one_level(self):
-        return self.eng.step(1, force_level=True)
-
-    def drain(self):
-        return self.eng.step(0)
-
-    def outgoing(self):
-        return self.eng.exchange_counts().astype(np.int64)
-
     def fill_result(self, level, val, evs, dbv):
         """Write this rank's objects into the global result arrays."""
         s, eng = self.s, self.eng

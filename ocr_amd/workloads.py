@@ -119,16 +119,6 @@ class LayeredPartition:
         if self.rank == 0:
             self.eng.event_satisfy_slot(np.array([self.start_guid], np.uint64))
 
-    # the protocol hooks resolve_distributed / resolve_lockstep use
-    def fire_one_level(self):
-        return self.eng.step(1, force_level=True)
-
-    def drain(self):
-        return self.eng.step(0)
-
-    def outgoing(self):
-        return self.eng.exchange_counts().astype(np.int64)
-
     @property
     def torch(self):
         import torch
