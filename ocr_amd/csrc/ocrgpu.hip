@@ -117,6 +117,7 @@ struct Dev {
     // cross-partition satisfies
     RemoteDst *rdst; u32 rdst_cap; SendRec *send; u32 send_cap, n_loc; u32 *send_cnt; // send_cnt[loc*32]
     u64 max_slots, max_edges, hash_tag_base;
+    u32 spread_wgs;             // k_step: a short work list is dealt out over this many workgroups
 };
 
 #define TOMB (~0ULL)
@@ -418,16 +419,23 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     S.r_base = r_total; S.q_base = q_total; S.cnt_r = &c->cnt_r[K % 3].v; S.cnt_q = &c->cnt_q[K % 3].v;
     u64 n_edt_sat = 0, n_evt_sat = 0, n_fired = 0;
     const u32 count = (S.mode == MODE_FIRE) ? S.r_end - S.r_begin : S.q_end - S.q_begin;
-    u32 part = (count + BLK - 1) / BLK; if (part > gridDim.x) part = gridDim.x; // 0 for a forced empty level
+    // Entries per workgroup per pass: spread a short list over the whole grid (a level of 255 EDTs with 255-waiter
+    // rows, or 512 pieces of a 1M-waiter row, must not land on one or two workgroups); BLK once the list is long.
+    // The spread stops at d.spread_wgs workgroups: every workgroup reserves its ready-log range with one atomic on
+    // the same counter, and same-address atomics serialise (~10 ns each: 2000 of them cost more than they save).
+    u32 per = (count + d.spread_wgs - 1) / d.spread_wgs;
+    if (per < 1) per = 1;
+    if (per > BLK) per = BLK;
+    u32 part = (count + per - 1) / per; if (part > gridDim.x) part = gridDim.x; // 0 for a forced empty level
     if (blockIdx.x >= part) return; // workgroups beyond the work leave at once
     STAMP(0);
 
     const bool body_first = d.n_loc > 1;
     if (S.mode == MODE_FIRE) {
         // ---- taskExecute + taskEpilogue for one level (hc-task.c:1864-2181, 1707-1862) ----
-        for (u32 cb = S.r_begin + blockIdx.x * BLK; cb < S.r_end; cb += gridDim.x * BLK) {
+        for (u32 cb = S.r_begin + blockIdx.x * per; cb < S.r_end; cb += gridDim.x * per) {
             u32 deg = 0; Seg sg = {0, 0, 0};
-            const u32 i = cb + threadIdx.x;
+            const u32 i = threadIdx.x < per ? cb + threadIdx.x : S.r_end;
             // Critical path per level: ready-log entry -> the EDT's 64-B line -> waiter row -> atomicSub -> log store.
             // The body's gathers (the DBs named by the pre-slot words, which sit in the same line) are issued
             // BEFORE the fan-out and consumed after it, so they ride under it.
@@ -502,9 +510,9 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
         }
     } else {
         // ---- queued satisfies: API calls, fired chained events, big-row pieces, direct EDT pre-slot satisfies ----
-        for (u32 cb = S.q_begin + blockIdx.x * BLK; cb < S.q_end; cb += gridDim.x * BLK) {
+        for (u32 cb = S.q_begin + blockIdx.x * per; cb < S.q_end; cb += gridDim.x * per) {
             u32 deg = 0; Seg sg = {0, 0, 0};
-            u32 i = cb + threadIdx.x;
+            u32 i = threadIdx.x < per ? cb + threadIdx.x : S.q_end;
             bool act = i < S.q_end;
             Rec r = {0, 0, 0, 0};
             bool ready = false, is_latch = false;
@@ -1032,6 +1040,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->have_events = false;
     e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
+    { const char *mp = getenv("OCRGPU_SPREAD_WGS"); u32 v = mp ? (u32)atoi(mp) : 256u; d.spread_wgs = v < 1 ? 1u : (v > MAX_GRID ? (u32)MAX_GRID : v); }
     d.max_edt = cfg->max_edt; d.max_evt = cfg->max_evt; d.max_db = cfg->max_db; d.location = cfg->location;
     d.max_slots = cfg->max_slots ? cfg->max_slots : 1; d.max_edges = cfg->max_edges ? cfg->max_edges : 1;
     d.max_levels = cfg->max_levels ? cfg->max_levels : (1u << 20);

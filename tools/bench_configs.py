@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Single-GPU measurements of the BASELINE configs other than bench.py's default (config 2): same step as bench.py
+(restore + satisfy(start) + resolve on a DAG resident in HBM), full-size parity against the CPU restatement, one JSON
+line per workload.  Not the contract bench: a measurement tool whose output is quoted in DESIGN.md s5.
+
+    python tools/bench_configs.py cholesky:256 stencil:2048:10 powerlaw:20000000 layered:10000000:100000
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def make(spec):
+    from ocr_amd import opstream as op
+    k, *a = spec.split(":")
+    a = [int(x) for x in a]
+    if k == "cholesky":
+        return op.cholesky_dag(a[0])
+    if k == "stencil":
+        return op.stencil_dag(a[0], a[1])
+    if k == "powerlaw":
+        return op.powerlaw_dag(a[0])
+    if k == "layered":
+        return op.layered_dag(a[0], a[1])
+    raise SystemExit(f"unknown workload {spec}")
+
+
+def run(spec, steps=3, warmup=1, parity=True):
+    from ocr_amd import engine, opstream
+    from ocr_amd import opstream as ops
+    t0 = time.time()
+    s = make(spec)
+    gen_s = time.time() - t0
+    assert int(s.main["op"][-1]) == ops.OP_SATISFY, "generators end with the start satisfy"
+    start_op = s.main[-1:]
+    built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
+    t0 = time.time()
+    prog = engine.StreamProgram(built, device=0, flags=engine.F_TIMING).build()
+    eng = prog.eng
+    eng.snapshot()
+    eng.sync()
+    build_s = time.time() - t0
+    start_guid = prog._guids(start_op["a"])
+    start_db = prog._guids(start_op["b"])
+
+    tm = {"restore": 0.0, "satisfy": 0.0, "resolve": 0.0}
+
+    def step(timed=False):
+        t0 = time.perf_counter()
+        eng.restore()
+        if timed:
+            eng.sync()
+        t1 = time.perf_counter()
+        eng.event_satisfy_slot(start_guid, start_db, start_op["slot"])
+        if timed:
+            eng.sync()
+        t2 = time.perf_counter()
+        st = eng.resolve()
+        t3 = time.perf_counter()
+        if timed:
+            tm["restore"] += t1 - t0
+            tm["satisfy"] += t2 - t1
+            tm["resolve"] += t3 - t2
+        return st
+
+    for _ in range(warmup):
+        st = step()
+    k0, l0 = eng.stats().step_kernel_ns, eng.stats().launches
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st = step()
+    eng.sync()
+    dt = (time.perf_counter() - t0) / steps
+    kern = (eng.stats().step_kernel_ns - k0) * 1e-9 / steps
+    launches = (eng.stats().launches - l0) / steps
+    assert sum(st.err) == 0, list(st.err)
+    for _ in range(steps):
+        st = step(timed=True)
+    n_sat = int(st.edt_sat + st.evt_sat)
+    out = {"workload": spec, "n_edt": int(s.n_edt), "n_evt": int(s.n_evt), "n_db": int(s.n_db), "fired": int(st.fired),
+           "levels": int(st.levels), "edt_sat": int(st.edt_sat), "evt_sat": int(st.evt_sat),
+           "meta_n_satisfactions": int(s.meta.get("n_satisfactions", 0)),
+           "ms_per_resolve": dt * 1e3, "ms_breakdown_synced": {k: round(v / steps * 1e3, 3) for k, v in tm.items()}, "ms_k_step": kern * 1e3, "launches": launches,
+           "sat_per_s": int(s.meta.get("n_satisfactions", n_sat)) / dt, "edts_per_s": int(st.fired) / dt,
+           "gen_s": round(gen_s, 2), "build_s": round(build_s, 2)}
+    if parity:
+        from oracle import ref as O            # checker only
+        t0 = time.time()
+        ref = O.run_restatement(s)
+        diff = prog.result().diff(ref)
+        out["parity"] = "bit-exact vs CPU restatement" if not diff else f"MISMATCH {diff[:3]}"
+        out["restatement_s"] = round(time.time() - t0, 2)
+    print(json.dumps(out), flush=True)
+    del prog, eng
+    return out
+
+
+if __name__ == "__main__":
+    specs = [a for a in sys.argv[1:] if not a.startswith("--")]
+    for sp in specs:
+        run(sp, parity="--no-parity" not in sys.argv)
