@@ -99,7 +99,7 @@ struct Dev {
     u32 *slots;                 // overflow pre-slot words (depc > 6): dbidx+1 (0 = NULL_GUID); bit31 = satisfied (nanny)
     // events: explicit [0,max_evt) in `evt`; the output event of EDT e is event max_evt+e and lives in edt[e]
     EvtRec *evt;
-    u64 *waiters;               // CSR payload: lo = dst ; hi = flags<<28 | (inline slot k | overflow slot index | latch slot)
+    u64 *waiters;               // CSR payload: lo = dst ; hi = flags<<28 | (pre-slot k of the EDT | latch slot)
     u32 *log_src; u64 *log_rec; // registration log the CSR is built from
     // datablocks (explicit [0,max_db) then the output DB of EDT e at max_db+e): {value, tag}
     ulonglong2 *db;
@@ -191,8 +191,10 @@ __device__ __forceinline__ u32 wave_append(u32 *tail, bool pred) {
 template <bool NANNY>
 __device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, u32 edt, u32 slot, u32 payload, u32 flags) {
     EdtLine *L = &d.edt[edt];
-    u32 *sp = (flags & RF_INLINE) ? &L->slot[slot] : &d.slots[slot];
     u32 word = (flags & RF_MODE_NULL) ? 0u : payload;
+    // overflow pre-slots (depc > 6): `slot` is relative, the base sits in the line the atomic is about to touch
+    u32 *sp = nullptr;
+    if (NANNY || !(flags & RF_PREFILLED)) sp = (flags & RF_INLINE) ? &L->slot[slot] : &d.slots[(size_t)L->slot[0] + slot];
     if (NANNY) {
         u32 old = atomicExch(sp, word | 0x80000000u);
         if (old & 0x80000000u) { atomicAdd(&d.ctrl->err[ERR_DOUBLE_SLOT], 1u); return false; }
@@ -646,7 +648,7 @@ __device__ __forceinline__ void q_push(const Dev &d, Rec r) {
 }
 __device__ __forceinline__ void bad_op(const Dev &d) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); }
 
-// resolve a destination guid into (idx, flags, encoded slot): inline slot k, overflow slot index, or event slot
+// resolve a destination guid into (idx, flags, encoded slot): pre-slot k of the EDT (flag INLINE when it lives in the line), or event slot
 __device__ bool resolve_dst(const Dev &d, u64 g, u32 slot, u32 &idx, u32 &flags, u32 &slot_out) {
     u64 v = gtab_get(d, g);
     if (!v) return false;
@@ -656,7 +658,7 @@ __device__ bool resolve_dst(const Dev &d, u64 g, u32 slot, u32 &idx, u32 &flags,
         u32 depc = d.edt[idx].depc;
         if (slot >= depc) return false;
         if (depc <= INLINE_SLOTS) { flags = RF_DST_EDT | RF_INLINE; slot_out = slot; }
-        else { flags = RF_DST_EDT; slot_out = d.edt[idx].slot[0] + slot; if (slot_out >= (1u << 28)) return false; }
+        else { flags = RF_DST_EDT; slot_out = slot; if (slot_out >= (1u << 28)) return false; } // relative to slot[0]
         return true;
     }
     if (!is_event_kind(k)) return false;
@@ -717,7 +719,7 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
             if (bk == OCRBODY_HASH) { known = true; word = d.max_db + se + 1; }
             else if (bk == OCRBODY_NOP) known = true;
         }
-        if (known) { pre = RF_PREFILLED; *((dflag & RF_INLINE) ? &d.edt[didx].slot[dslot] : &d.slots[dslot]) = word; }
+        if (known) { pre = RF_PREFILLED; *((dflag & RF_INLINE) ? &d.edt[didx].slot[dslot] : &d.slots[(size_t)d.edt[didx].slot[0] + dslot]) = word; }
     }
     u32 li = atomicAdd(&d.ctrl->log_tail, 1u);
     if (li >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
