@@ -49,7 +49,9 @@ enum {
 enum {
     OCRBODY_NOP = 0,  /* returns NULL_GUID                                              */
     OCRBODY_HASH = 1, /* folds id + every depv[i] payload into a u64, stores it in a new DB, returns that DB */
-    OCRBODY_FWD0 = 2  /* returns depv[0].guid                                           */
+    OCRBODY_FWD0 = 2, /* returns depv[0].guid                                           */
+    OCRBODY_HOST = 3  /* GPU engine only: the body is host code; the EDT is handed out by ocrgpu_pop_ready and its
+                         epilogue (output-event satisfy) comes back through ocrgpu_event_satisfy_slot */
 };
 #define OCRBODY_KIND(b) ((b) & 0xFF)
 #define OCRBODY_F_OUTEVT 0x100u /* created with an output event (ONCE, hc-task.c:955)  */

@@ -28,6 +28,13 @@ extern "C" {
 typedef struct ocrgpu_engine ocrgpu_engine_t;
 
 enum { OCRGPU_HOST = 0, OCRGPU_DEVICE = 1 };
+/* OR into `where` of ocrgpu_event_create / ocrgpu_db_create / ocrgpu_edt_create: the guid arrays are INPUTS holding
+ * guids the caller took from ocrgpu_guid_reserve earlier (the reference's guidReserve + labeled create,
+ * ocr/src/inc/ocr-guid.h:127-144; GUID_PROP_IS_LABELED ocr/inc/ocr-types.h:504).  Lets a host shim hand a guid back
+ * from ocrEdtCreate at once and create the object later in a batch (deferred API, hc-policy.c:1523-1720).
+ * ocrgpu_edt_create: guids_out = EDT guids, outevt_guids_out = output-event guids (kind ONCE; 0 or NULL = none),
+ * outdb_guids_out is ignored. */
+#define OCRGPU_GUIDS_GIVEN 4
 
 enum {
     OCRGPU_OK = 0,
@@ -147,6 +154,19 @@ int ocrgpu_resolve(ocrgpu_engine_t *e, uint64_t max_levels, ocrgpu_stats_t *stat
 #define OCRGPU_STEP_FORCE_LEVEL 1u
 int ocrgpu_step(ocrgpu_engine_t *e, uint32_t fire_levels, uint32_t flags, uint64_t *has_ready_out,
                 uint64_t *pending_records_out, uint32_t *send_counts_out /* host [n_locations] or NULL */);
+
+/* EDTs whose body is host code (OCRBODY_HOST): GET_WORK + the depv hand-over of taskExecute
+ * (hcSchedulerHeuristicGetEdt hc-scheduler-heuristic.c:148-199, workpile pop ocr-workpile.h:39-84, hc-task.c:1864-1916).
+ * Returns the HOST EDTs that fired since the previous call (any order): param0_out[i] = paramv[0] (the caller's task
+ * handle), depc_out[i], and depv of EDT i at dep_*_out[dep_first_out[i] .. +depc_out[i]): guid = the `tag` and value =
+ * the `value` the datablock was created with (a shim stores guid and host pointer there), both 0 for NULL_GUID.
+ * The engine does not run an epilogue for such an EDT: the caller satisfies its output event
+ * (ocrgpu_event_satisfy_slot) when the body returns (taskEpilogue, hc-task.c:1788-1831).
+ * When more is ready than fits, returns OCRGPU_ENOMEM with the needed sizes in *n_edts_out / *n_deps_out and pops
+ * nothing.  All arrays are HOST memory. */
+int ocrgpu_pop_ready(ocrgpu_engine_t *e, uint64_t max_edts, uint64_t max_deps, uint64_t *n_edts_out, uint64_t *n_deps_out,
+                     uint64_t *param0_out, uint32_t *depc_out, uint32_t *dep_first_out, uint64_t *dep_guid_out,
+                     uint64_t *dep_value_out);
 
 /* ---- cross-partition satisfies (replace ocrCommPlatformFcts_t.sendMessage/pollMessage for PD_MSG_DEP_SATISFY,
  *      ocr/src/inc/ocr-comm-platform.h:55-199, mpi-comm-platform.c:1055, hc-dist-policy.c:2208).  The engine fills

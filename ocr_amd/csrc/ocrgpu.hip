@@ -467,7 +467,8 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                 ++n_fired;
                 // With other partitions around, a satisfy may carry this EDT's output DB away by value in this very
                 // launch, so the body runs first; on a single partition it runs after the fan-out (off the critical path).
-                if (body_first) run_body(d, e, id, depc, sl, gb);
+                const bool host_body = kind == OCRBODY_HOST; // taskExecute happens on the host (ocrgpu_pop_ready)
+                if (body_first && !host_body) run_body(d, e, id, depc, sl, gb);
                 if (body & BODY_F_SCRIPT) { // the body's own ocrEventSatisfySlot / ocrEventDestroy calls
                     u32 sb = d.edt_script_begin[e], sn = d.edt_script_len[e];
                     for (u32 k = 0; k < sn; ++k) {
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                         }
                     }
                 }
-                if (body & OCRBODY_F_OUTEVT) { // epilogue: satisfy the ONCE output event with the returned guid
+                if ((body & OCRBODY_F_OUTEVT) && !host_body) { // epilogue: satisfy the ONCE output event with the returned guid
                     ++n_evt_sat;
                     bool ok = true;
                     if (NANNY) ok = evt_satisfy_simple(d, x, OCREVT_ONCE, ret);
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (total) fan_out<NANNY>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             else __syncthreads();
             STAMP(3);
-            if (mine && !body_first) run_body(d, e, id, depc, sl, gb);
+            if (mine && !body_first && OCRBODY_KIND(body) != OCRBODY_HOST) run_body(d, e, id, depc, sl, gb);
         }
     } else {
         // ---- queued satisfies: API calls, fired chained events, big-row pieces, direct EDT pre-slot satisfies ----
@@ -590,23 +591,31 @@ __global__ void k_end(Dev d, u32 K) {
 // ------------------------------------------------------------------------------------------------
 // construction kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void k_event_create(Dev d, u64 n, const u32 *kind, const s32 *arg, u32 first_idx, u64 first_counter, u64 *guids_out) {
+// `gin` != nullptr: the caller chose the guids (handed out earlier by ocrgpu_guid_reserve -- the reference's
+// guidReserve + labeled create, ocr-guid.h:127-144); a guid of the wrong kind or location is a malformed op.
+__device__ __forceinline__ bool given_ok(const Dev &d, u64 g, u32 kind) {
+    if (OCRGPU_GUID_KIND(g) == kind && OCRGPU_GUID_LOCATION(g) == d.location && OCRGPU_GUID_COUNTER(g) != 0) return true;
+    atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return false;
+}
+__global__ void k_event_create(Dev d, u64 n, const u32 *kind, const s32 *arg, u32 first_idx, u64 first_counter, const u64 *gin, u64 *guids_out) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 k = kind[i], x = first_idx + (u32)i;
     d.evt[x] = EvtRec{0, 0, ST_LIVE | (k << 8), k == OCREVT_LATCH ? arg[i] : 0};
-    u64 g = mkguid(d.location, evt_kind_to_guid_kind(k), first_counter + i);
+    u64 g = gin ? gin[i] : mkguid(d.location, evt_kind_to_guid_kind(k), first_counter + i);
+    if (gin && !given_ok(d, g, evt_kind_to_guid_kind(k))) return;
     gtab_put(d, g, (u64)x + 1);
-    guids_out[i] = g;
+    if (guids_out) guids_out[i] = g;
 }
-__global__ void k_db_create(Dev d, u64 n, const u64 *value, const u64 *tag, u32 first_idx, u64 first_counter, u64 *guids_out) {
+__global__ void k_db_create(Dev d, u64 n, const u64 *value, const u64 *tag, u32 first_idx, u64 first_counter, const u64 *gin, u64 *guids_out) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 x = first_idx + (u32)i;
     d.db[x] = make_ulonglong2(value[i], tag ? tag[i] : (u64)x);
-    u64 g = mkguid(d.location, OCRGPU_KIND_DB, first_counter + i);
+    u64 g = gin ? gin[i] : mkguid(d.location, OCRGPU_KIND_DB, first_counter + i);
+    if (gin && !given_ok(d, g, OCRGPU_KIND_DB)) return;
     gtab_put(d, g, (u64)x + 1);
-    guids_out[i] = g;
+    if (guids_out) guids_out[i] = g;
 }
 // overflow slot words an EDT needs (0 when its pre-slots fit the line)
 __global__ void k_ovf_counts(u64 n, const u32 *depc, u32 *ovf) {
@@ -615,7 +624,8 @@ __global__ void k_ovf_counts(u64 n, const u32 *depc, u32 *ovf) {
 }
 // slot_ovf[] already holds the exclusive scan of the overflow counts (+ overflow slots in use)
 __global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, const u64 *param0, const u32 *slot_ovf,
-                             u32 first_idx, u64 first_counter, u64 *guids_out, u64 *outevt_out, u64 *outdb_out) {
+                             u32 first_idx, u64 first_counter, const u64 *gin, const u64 *oevt_in,
+                             u64 *guids_out, u64 *outevt_out, u64 *outdb_out) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 e = first_idx + (u32)i, dc = depc[i], b = body[i] & 0xFFFFu;
@@ -627,18 +637,23 @@ __global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, con
     for (u32 k = 0; k < INLINE_SLOTS; ++k) L.slot[k] = 0;
     if (dc > INLINE_SLOTS) L.slot[0] = slot_ovf[i];
     d.edt[e] = L;
-    u64 g = mkguid(d.location, OCRGPU_KIND_EDT, first_counter + 3 * i);
-    gtab_put(d, g, (u64)e + 1);
-    guids_out[i] = g;
-    u64 ge = 0;
-    if (b & OCRBODY_F_OUTEVT) {
-        ge = mkguid(d.location, OCRGPU_KIND_EVT_ONCE, first_counter + 3 * i + 1);
-        gtab_put(d, ge, (u64)(d.max_evt + e) + 1);
+    if (gin) { // caller-chosen guids: the EDT's, and (optionally) its output event's; no guid for an output DB
+        if (given_ok(d, gin[i], OCRGPU_KIND_EDT)) gtab_put(d, gin[i], (u64)e + 1);
+        if ((b & OCRBODY_F_OUTEVT) && oevt_in && oevt_in[i] && given_ok(d, oevt_in[i], OCRGPU_KIND_EVT_ONCE)) gtab_put(d, oevt_in[i], (u64)(d.max_evt + e) + 1);
+    } else {
+        u64 g = mkguid(d.location, OCRGPU_KIND_EDT, first_counter + 3 * i);
+        gtab_put(d, g, (u64)e + 1);
+        guids_out[i] = g;
+        u64 ge = 0;
+        if (b & OCRBODY_F_OUTEVT) {
+            ge = mkguid(d.location, OCRGPU_KIND_EVT_ONCE, first_counter + 3 * i + 1);
+            gtab_put(d, ge, (u64)(d.max_evt + e) + 1);
+        }
+        if (outevt_out) outevt_out[i] = ge;
+        u64 gd = mkguid(d.location, OCRGPU_KIND_DB, first_counter + 3 * i + 2);
+        gtab_put(d, gd, (u64)(d.max_db + e) + 1);
+        if (outdb_out) outdb_out[i] = gd;
     }
-    if (outevt_out) outevt_out[i] = ge;
-    u64 gd = mkguid(d.location, OCRGPU_KIND_DB, first_counter + 3 * i + 2);
-    gtab_put(d, gd, (u64)(d.max_db + e) + 1);
-    if (outdb_out) outdb_out[i] = gd;
     if (dc == 0) { u32 ri = atomicAdd(&d.ctrl->r_tail, 1u); d.fired[ri] = e; } // fires at creation (hc-task.c:1129-1134)
 }
 
@@ -806,6 +821,30 @@ __global__ void k_exchange_apply(Dev d, u64 n, const SendRec *recs, u32 proxy_ba
 __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
 __global__ void k_exchange_counts(Dev d, u32 *out) { if (threadIdx.x < d.n_loc) { u32 c = d.send_cnt[threadIdx.x * 32]; out[threadIdx.x] = c > d.send_cap ? d.send_cap : c; } }
 
+// SCHED_GET_WORK for EDTs whose bodies run on the host (hcSchedulerHeuristicGetEdt, hc-scheduler-heuristic.c:148-199,
+// feeding taskExecute hc-task.c:1864): compact the OCRBODY_HOST EDTs of fired[begin,end) with what their body needs --
+// paramv[0] and depv[] as {guid, value} of each pre-slot's datablock (ocrEdtDep_t, hc-task.c:680-690).
+__global__ void k_pop_ready(Dev d, u32 begin, u32 end, u32 max_edts, u32 max_deps, u32 *cnt, u64 *param0_out, u32 *depc_out,
+                            u32 *dep_first_out, u64 *dep_guid_out, u64 *dep_value_out) {
+    for (u64 i = begin + blockIdx.x * (u64)blockDim.x + threadIdx.x; i < end; i += (u64)gridDim.x * blockDim.x) {
+        u32 e = d.fired[i];
+        if (e == INVALID) continue;
+        const EdtLine *L = &d.edt[e];
+        if (OCRBODY_KIND(L->body) != OCRBODY_HOST) continue;
+        u32 depc = L->depc;
+        u32 pos = atomicAdd(&cnt[0], 1u), dpos = atomicAdd(&cnt[1], depc);
+        if (pos >= max_edts || (u64)dpos + depc > max_deps) continue; // the caller sees the totals and comes back with room
+        param0_out[pos] = L->param0; depc_out[pos] = depc; dep_first_out[pos] = dpos;
+        const u32 *sl = depc <= INLINE_SLOTS ? L->slot : d.slots + L->slot[0];
+        for (u32 k = 0; k < depc; ++k) {
+            u32 p = sl[k] & 0x7FFFFFFFu;
+            ulonglong2 b = make_ulonglong2(0, 0);
+            if (p) { b = db_gather(d, p); if (p - 1 >= d.max_db) b.y = 0; } // explicit DBs carry their guid in the tag
+            dep_guid_out[dpos + k] = b.y; dep_value_out[dpos + k] = b.x;
+        }
+    }
+}
+
 // ---- CSR (re)build from the registration log: count -> scan -> fill --------------------------------
 __global__ void k_csr_clear(Dev d, u32 n_evt_total) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -941,6 +980,7 @@ struct ocrgpu_engine {
     hipEvent_t ev0, ev1; bool have_events; u32 step_grid; u32 launch_index; u64 fired_cap; bool defer_drain; u32 *send_cnt_dev;
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
     u32 *pinned_done;
+    u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
 };
 
 static int dalloc(ocrgpu_engine *e, void **p, size_t bytes, bool zero = true) {
@@ -1040,7 +1080,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->have_events = false;
-    e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
+    e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->pop_cursor = e->snap_pop_cursor = 0; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
     { const char *mp = getenv("OCRGPU_SPREAD_WGS"); u32 v = mp ? (u32)atoi(mp) : 256u; d.spread_wgs = v < 1 ? 1u : (v > MAX_GRID ? (u32)MAX_GRID : v); }
     d.max_edt = cfg->max_edt; d.max_evt = cfg->max_evt; d.max_db = cfg->max_db; d.location = cfg->location;
@@ -1245,12 +1285,15 @@ extern "C" int ocrgpu_event_create(ocrgpu_engine_t *e, u64 n, const u32 *kind, c
     if (n == 0) return 0;
     if (!kind || !arg || !guids_out) FAIL(OCRGPU_EINVAL, "null array");
     if ((u64)e->n_evt + n > e->cfg.max_evt) FAIL(OCRGPU_ENOMEM, "max_evt=%u exhausted", e->cfg.max_evt);
+    const bool given = (where & OCRGPU_GUIDS_GIVEN) != 0; where &= 1;
     int r = stage_reserve(e, 2 * rup(4 * n) + rup(8 * n)); if (r) return r;
-    const u32 *dk; const s32 *da; u64 *dg;
-    if ((r = stage_in(e, kind, n, where, &dk)) || (r = stage_in(e, arg, n, where, &da)) || (r = stage_out_alloc(e, guids_out, n, where, &dg))) return r;
-    k_event_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dk, da, e->n_evt, e->counter, dg);
-    e->n_evt += (u32)n; e->counter += n;
-    if ((r = stage_out_copy(e, guids_out, dg, n, where))) return r;
+    const u32 *dk; const s32 *da; u64 *dg = nullptr; const u64 *dgin = nullptr;
+    if ((r = stage_in(e, kind, n, where, &dk)) || (r = stage_in(e, arg, n, where, &da))) return r;
+    if (given) r = stage_in(e, (const u64 *)guids_out, n, where, &dgin); else r = stage_out_alloc(e, guids_out, n, where, &dg);
+    if (r) return r;
+    k_event_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dk, da, e->n_evt, e->counter, dgin, dg);
+    e->n_evt += (u32)n; if (!given) e->counter += n;
+    if (!given && (r = stage_out_copy(e, guids_out, dg, n, where))) return r;
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
@@ -1259,12 +1302,15 @@ extern "C" int ocrgpu_db_create(ocrgpu_engine_t *e, u64 n, const u64 *value, con
     if (n == 0) return 0;
     if (!value || !guids_out) FAIL(OCRGPU_EINVAL, "null array");
     if ((u64)e->n_db + n > e->cfg.max_db) FAIL(OCRGPU_ENOMEM, "max_db=%u exhausted", e->cfg.max_db);
+    const bool given = (where & OCRGPU_GUIDS_GIVEN) != 0; where &= 1;
     int r = stage_reserve(e, 3 * rup(8 * n)); if (r) return r;
-    const u64 *dv, *dt; u64 *dg;
-    if ((r = stage_in(e, value, n, where, &dv)) || (r = stage_in(e, tag, n, where, &dt)) || (r = stage_out_alloc(e, guids_out, n, where, &dg))) return r;
-    k_db_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dv, dt, e->n_db, e->counter, dg);
-    e->n_db += (u32)n; e->counter += n;
-    if ((r = stage_out_copy(e, guids_out, dg, n, where))) return r;
+    const u64 *dv, *dt; u64 *dg = nullptr; const u64 *dgin = nullptr;
+    if ((r = stage_in(e, value, n, where, &dv)) || (r = stage_in(e, tag, n, where, &dt))) return r;
+    if (given) r = stage_in(e, (const u64 *)guids_out, n, where, &dgin); else r = stage_out_alloc(e, guids_out, n, where, &dg);
+    if (r) return r;
+    k_db_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dv, dt, e->n_db, e->counter, dgin, dg);
+    e->n_db += (u32)n; if (!given) e->counter += n;
+    if (!given && (r = stage_out_copy(e, guids_out, dg, n, where))) return r;
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
@@ -1274,11 +1320,14 @@ extern "C" int ocrgpu_edt_create(ocrgpu_engine_t *e, u64 n, const u32 *depc, con
     if (n == 0) return 0;
     if (!depc || !body || !guids_out) FAIL(OCRGPU_EINVAL, "null array");
     if ((u64)e->n_edt + n > e->cfg.max_edt) FAIL(OCRGPU_ENOMEM, "max_edt=%u exhausted", e->cfg.max_edt);
+    const bool given = (where & OCRGPU_GUIDS_GIVEN) != 0; where &= 1;
     int r = stage_reserve(e, 4 * rup(4 * n) + 4 * rup(8 * n) + 256); if (r) return r;
-    const u32 *dd, *db; const u64 *dp; u64 *dg, *doe, *dod; u32 *dsb, *dtot;
-    if ((r = stage_in(e, depc, n, where, &dd)) || (r = stage_in(e, body, n, where, &db)) || (r = stage_in(e, param0, n, where, &dp)) ||
-        (r = stage_out_alloc(e, guids_out, n, where, &dg)) || (r = stage_out_alloc(e, outevt_out, n, where, &doe)) ||
-        (r = stage_out_alloc(e, outdb_out, n, where, &dod))) return r;
+    const u32 *dd, *db; const u64 *dp; u64 *dg = nullptr, *doe = nullptr, *dod = nullptr; u32 *dsb, *dtot; const u64 *dgin = nullptr, *doin = nullptr;
+    if ((r = stage_in(e, depc, n, where, &dd)) || (r = stage_in(e, body, n, where, &db)) || (r = stage_in(e, param0, n, where, &dp))) return r;
+    if (given) {
+        if ((r = stage_in(e, (const u64 *)guids_out, n, where, &dgin)) || (r = stage_in(e, (const u64 *)outevt_out, n, where, &doin))) return r;
+    } else if ((r = stage_out_alloc(e, guids_out, n, where, &dg)) || (r = stage_out_alloc(e, outevt_out, n, where, &doe)) ||
+               (r = stage_out_alloc(e, outdb_out, n, where, &dod))) return r;
     dsb = (u32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += rup(4 * n);
     dtot = (u32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += 256;
     u32 *dovf = (u32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += rup(4 * n);
@@ -1288,10 +1337,10 @@ extern "C" int ocrgpu_edt_create(ocrgpu_engine_t *e, u64 n, const u32 *depc, con
     HIPCHK(hipStreamSynchronize(e->stream));
     u64 add = e->pinned_done[33000] - (u32)e->n_slots; // the scan was seeded with the slots already in use
     if (e->n_slots + add > e->d.max_slots) FAIL(OCRGPU_ENOMEM, "max_slots=%llu exhausted", (unsigned long long)e->d.max_slots);
-    k_edt_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dd, db, dp, dsb, e->n_edt, e->counter, dg, doe, dod);
-    e->n_edt += (u32)n; e->n_slots += add; e->counter += 3 * n;
-    if ((r = stage_out_copy(e, guids_out, dg, n, where)) || (r = stage_out_copy(e, outevt_out, doe, n, where)) ||
-        (r = stage_out_copy(e, outdb_out, dod, n, where))) return r;
+    k_edt_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dd, db, dp, dsb, e->n_edt, e->counter, dgin, doin, dg, doe, dod);
+    e->n_edt += (u32)n; e->n_slots += add; if (!given) e->counter += 3 * n;
+    if (!given && ((r = stage_out_copy(e, guids_out, dg, n, where)) || (r = stage_out_copy(e, outevt_out, doe, n, where)) ||
+                   (r = stage_out_copy(e, outdb_out, dod, n, where)))) return r;
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
@@ -1394,6 +1443,45 @@ extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *
     return 0;
 }
 
+extern "C" int ocrgpu_pop_ready(ocrgpu_engine_t *e, u64 max_edts, u64 max_deps, u64 *n_edts_out, u64 *n_deps_out, u64 *param0_out,
+                                u32 *depc_out, u32 *dep_first_out, u64 *dep_guid_out, u64 *dep_value_out) {
+    ENTER(e);
+    if (!n_edts_out || !n_deps_out) FAIL(OCRGPU_EINVAL, "null argument");
+    if ((max_edts && (!param0_out || !depc_out || !dep_first_out)) || (max_deps && (!dep_guid_out || !dep_value_out))) FAIL(OCRGPU_EINVAL, "null array");
+    if (max_edts > 0xFFFFFFFFull || max_deps > 0xFFFFFFFFull) FAIL(OCRGPU_EINVAL, "capacity above 2^32");
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33010, &e->d.ctrl->r_end, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const u32 r_end = e->pinned_done[33010];
+    *n_edts_out = 0; *n_deps_out = 0;
+    if (r_end <= e->pop_cursor) return 0;
+    int r = stage_reserve(e, 256 + rup(8 * max_edts) + 2 * rup(4 * max_edts) + 2 * rup(8 * max_deps)); if (r) return r;
+    auto carve = [&](size_t bytes) { char *p = e->stage_dev + e->stage_dev_off; e->stage_dev_off += rup(bytes); return p; };
+    u32 *cnt = (u32 *)carve(256);
+    u64 *dp0 = (u64 *)carve(8 * max_edts); u32 *ddc = (u32 *)carve(4 * max_edts), *ddf = (u32 *)carve(4 * max_edts);
+    u64 *dgd = (u64 *)carve(8 * max_deps), *dvl = (u64 *)carve(8 * max_deps);
+    HIPCHK(hipMemsetAsync(cnt, 0, 8, e->stream));
+    u64 span = r_end - e->pop_cursor; u32 g = nblk(span); if (g > 4096) g = 4096;
+    k_pop_ready<<<g, 256, 0, e->stream>>>(e->d, e->pop_cursor, r_end, (u32)max_edts, (u32)max_deps, cnt, dp0, ddc, ddf, dgd, dvl);
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33012, cnt, 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const u64 ne = e->pinned_done[33012], nd = e->pinned_done[33013];
+    *n_edts_out = ne; *n_deps_out = nd;
+    if (ne > max_edts || nd > max_deps) FAIL(OCRGPU_ENOMEM, "pop_ready: %llu EDTs / %llu deps are ready, room for %llu / %llu (nothing was popped)",
+                                              (unsigned long long)ne, (unsigned long long)nd, (unsigned long long)max_edts, (unsigned long long)max_deps);
+    if (ne) {
+        HIPCHK(hipMemcpyAsync(param0_out, dp0, 8 * ne, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(depc_out, ddc, 4 * ne, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(dep_first_out, ddf, 4 * ne, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (nd) {
+        HIPCHK(hipMemcpyAsync(dep_guid_out, dgd, 8 * nd, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(dep_value_out, dvl, 8 * nd, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->pop_cursor = r_end;
+    return 0;
+}
+
 // ---- cross-partition exchange (replaces the comm-platform's sendMessage/pollMessage for DEP_SATISFY,
 //      ocr/src/inc/ocr-comm-platform.h:55-199; the transport itself -- RCCL all-to-all -- is the caller's) ----
 extern "C" int ocrgpu_exchange_config(ocrgpu_engine_t *e, u32 n_locations, void *send_dev_buf, u64 records_per_dest, u64 max_remote_dsts) {
@@ -1453,7 +1541,7 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     s.n_fired_entries = e->pinned_done[33012];
     HIPCHK(hipMalloc((void **)&s.fired, 4 * (size_t)s.n_fired_entries + 16));
     HIPCHK(hipMalloc((void **)&s.ctrl, sizeof(Ctrl)));
-    s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt; s.n_db = e->n_db;
+    s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt; s.n_db = e->n_db; e->snap_pop_cursor = e->pop_cursor;
     HIPCHK(hipMemcpyAsync(s.edt, d.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(s.evt, d.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(s.fired, d.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
@@ -1465,6 +1553,7 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     Dev &d = e->d; Snapshot &s = e->snap;
     if (!s.valid) FAIL(OCRGPU_EINVAL, "no snapshot taken");
     if (s.n_edt != e->n_edt || s.n_evt != e->n_evt) FAIL(OCRGPU_EINVAL, "objects were created after the snapshot");
+    e->pop_cursor = e->snap_pop_cursor;
     e->n_db = s.n_db; // proxy datablocks cloned from other partitions since the snapshot are dropped
     if (e->d.send_cnt) k_exchange_reset<<<1, 1024, 0, e->stream>>>(e->d);
     HIPCHK(hipMemcpyAsync(d.edt, s.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));

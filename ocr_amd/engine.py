@@ -19,7 +19,10 @@ from . import opstream as ops
 from .opstream import OpStream, Result
 
 HOST, DEVICE = 0, 1
+GUIDS_GIVEN = 4   # OR into `where` of the create calls: guid arrays are inputs (ocrgpu.h)
 F_NANNY, F_TIMING = 1, 2
+# ocrGuidKind values in the guid KIND bits (ocrgpu.h)
+KIND_DB, KIND_EDT, KIND_EVT_ONCE, KIND_EVT_COUNTED, KIND_EVT_IDEM, KIND_EVT_STICKY, KIND_EVT_LATCH = 2, 3, 17, 18, 19, 21, 22
 _LIB_PATH = os.environ.get("OCRGPU_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libocrgpu.so")
 
 
@@ -52,7 +55,7 @@ EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error
            "ocrgpu_guid_reserve", "ocrgpu_guid_put", "ocrgpu_guid_get", "ocrgpu_guid_remove",
            "ocrgpu_event_create", "ocrgpu_db_create", "ocrgpu_edt_create", "ocrgpu_edt_set_scripts",
            "ocrgpu_set_hash_tag_base", "ocrgpu_add_dependence", "ocrgpu_event_satisfy_slot", "ocrgpu_event_destroy",
-           "ocrgpu_resolve", "ocrgpu_step", "ocrgpu_exchange_config", "ocrgpu_exchange_counts",
+           "ocrgpu_resolve", "ocrgpu_step", "ocrgpu_pop_ready", "ocrgpu_exchange_config", "ocrgpu_exchange_counts",
            "ocrgpu_exchange_reset", "ocrgpu_exchange_apply", "ocrgpu_snapshot", "ocrgpu_restore", "ocrgpu_sync", "ocrgpu_read_edts",
            "ocrgpu_read_events", "ocrgpu_read_dbs", "ocrgpu_read_fired", "ocrgpu_get_stats"]
 
@@ -133,28 +136,54 @@ class Engine:
         self._chk(self.lib.ocrgpu_guid_remove(self.h, C.c_uint64(len(guids)), _ptr(guids), HOST))
 
     # ---- objects ----
-    def event_create(self, kind, arg=None):
+    def event_create(self, kind, arg=None, guids=None):
+        """guids: caller-chosen guids from guid_reserve (OCRGPU_GUIDS_GIVEN) instead of engine-made ones."""
         kind = np.ascontiguousarray(kind, np.uint32)
         arg = np.zeros(len(kind), np.int32) if arg is None else np.ascontiguousarray(arg, np.int32)
-        out = np.empty(len(kind), dtype=np.uint64)
-        self._chk(self.lib.ocrgpu_event_create(self.h, C.c_uint64(len(kind)), _ptr(kind), _ptr(arg), _ptr(out), HOST))
+        given = guids is not None
+        out = np.ascontiguousarray(guids, np.uint64) if given else np.empty(len(kind), dtype=np.uint64)
+        self._chk(self.lib.ocrgpu_event_create(self.h, C.c_uint64(len(kind)), _ptr(kind), _ptr(arg), _ptr(out),
+                                               HOST | (GUIDS_GIVEN if given else 0)))
         return out
 
-    def db_create(self, value, tag=None):
+    def db_create(self, value, tag=None, guids=None):
         value = np.ascontiguousarray(value, np.uint64)
         tag = None if tag is None else np.ascontiguousarray(tag, np.uint64)
-        out = np.empty(len(value), dtype=np.uint64)
-        self._chk(self.lib.ocrgpu_db_create(self.h, C.c_uint64(len(value)), _ptr(value), _ptr(tag), _ptr(out), HOST))
+        given = guids is not None
+        out = np.ascontiguousarray(guids, np.uint64) if given else np.empty(len(value), dtype=np.uint64)
+        self._chk(self.lib.ocrgpu_db_create(self.h, C.c_uint64(len(value)), _ptr(value), _ptr(tag), _ptr(out),
+                                            HOST | (GUIDS_GIVEN if given else 0)))
         return out
 
-    def edt_create(self, depc, body, param0=None):
+    def edt_create(self, depc, body, param0=None, guids=None, outevt_guids=None):
         depc, body = np.ascontiguousarray(depc, np.uint32), np.ascontiguousarray(body, np.uint32)
         param0 = None if param0 is None else np.ascontiguousarray(param0, np.uint64)
         n = len(depc)
+        if guids is not None:
+            g = np.ascontiguousarray(guids, np.uint64)
+            oe = None if outevt_guids is None else np.ascontiguousarray(outevt_guids, np.uint64)
+            self._chk(self.lib.ocrgpu_edt_create(self.h, C.c_uint64(n), _ptr(depc), _ptr(body), _ptr(param0), _ptr(g),
+                                                 _ptr(oe), None, HOST | GUIDS_GIVEN))
+            return g, oe, None
         g, oe, od = (np.empty(n, dtype=np.uint64) for _ in range(3))
         self._chk(self.lib.ocrgpu_edt_create(self.h, C.c_uint64(n), _ptr(depc), _ptr(body), _ptr(param0), _ptr(g),
                                              _ptr(oe), _ptr(od), HOST))
         return g, oe, od
+
+    def pop_ready(self, max_edts=1 << 16, max_deps=1 << 18):
+        """EDTs with OCRBODY_HOST bodies that fired since the last call: (param0[n], depc[n], dep_first[n],
+        dep_guid[m], dep_value[m]); grows its buffers and retries when more is ready than fits."""
+        while True:
+            p0, dc, df = np.empty(max_edts, np.uint64), np.empty(max_edts, np.uint32), np.empty(max_edts, np.uint32)
+            dg, dv = np.empty(max_deps, np.uint64), np.empty(max_deps, np.uint64)
+            ne, nd = C.c_uint64(0), C.c_uint64(0)
+            rc = self.lib.ocrgpu_pop_ready(self.h, C.c_uint64(max_edts), C.c_uint64(max_deps), C.byref(ne), C.byref(nd),
+                                           _ptr(p0), _ptr(dc), _ptr(df), _ptr(dg), _ptr(dv))
+            if rc == -12 and (ne.value > max_edts or nd.value > max_deps):
+                max_edts, max_deps = max(max_edts, ne.value), max(max_deps, nd.value)
+                continue
+            self._chk(rc)
+            return p0[:ne.value], dc[:ne.value], df[:ne.value], dg[:nd.value], dv[:nd.value]
 
     def edt_set_scripts(self, edt, begin, length, script_ops):
         edt = np.ascontiguousarray(edt, np.uint64)
