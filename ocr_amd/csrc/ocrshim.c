@@ -1,0 +1,425 @@
+/*
+ * libocrshim -- host side of libocrgpu for unmodified OCR programs.
+ *
+ * The program's EDT bodies are ordinary host C.  All dependence bookkeeping -- events, latches, pre-slot counting,
+ * the ready set -- lives in the MI355X engine behind include/ocrgpu.h.  The loop below is the reference's worker
+ * loop (hc-worker.c:52-216: get work -> taskExecute -> taskEpilogue) turned level-synchronous:
+ *
+ *     flush the API calls the last level's bodies made (batched, see below) -> ocrgpu_step(one level)
+ *     -> ocrgpu_pop_ready: the EDTs that fired, with paramv handle and depv -> run their bodies -> repeat
+ *
+ * API calls made inside a body are DEFERRED, the execution model the reference implements behind
+ * ENABLE_OCR_API_DEFERRABLE (hc-policy.c:1523-1720, hc-task.c:1672-1698): the call returns at once (guids come from
+ * blocks reserved with ocrgpu_guid_reserve), is queued, and takes effect when the EDT has returned.  The queue is
+ * flushed as batched C-ABI calls.  Program order INSIDE one EDT is kept: every op carries a round number that grows
+ * whenever the EDT issues an op of an earlier class than its previous one (classes: event create, DB create, EDT
+ * create, add-dependence, satisfy, event destroy, DB destroy) or touches the same event twice in a way that does not
+ * commute; the flush runs round by round, class by class.  Order BETWEEN EDTs of one level is not defined by OCR
+ * (they run concurrently in the reference).
+ *
+ * Finish EDTs (EDT_PROP_FINISH) follow hc-task.c:1071-1078,1917-1986,1788-1831: a LATCH (counter 1) per finish scope,
+ * INCR when a child is created in the scope, DECR in every child's epilogue and in the finish EDT's own; the latch
+ * satisfies the finish EDT's output event and DECRs the enclosing scope's latch.
+ *
+ * Not thread safe; bodies run on the calling thread.  No CPU fallback: without a GPU ocrgpu_init fails and the
+ * program exits with an error.
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "ocr.h"
+#include "ocrgpu.h"
+#include "ocr_opstream.h"
+
+/* ---- small helpers ---------------------------------------------------------------------------------------- */
+static void die(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    fprintf(stderr, "ocrshim: "); vfprintf(stderr, fmt, ap); fprintf(stderr, "\n");
+    va_end(ap);
+    exit(70);
+}
+static void *xrealloc(void *p, size_t n) { void *q = realloc(p, n ? n : 1); if (!q) die("out of host memory"); return q; }
+#define GROW(arr, n, cap) do { if ((n) >= (cap)) { (cap) = (cap) ? 2 * (cap) : 1024; (arr) = xrealloc((arr), (cap) * sizeof *(arr)); } } while (0)
+#define CHK(call) do { int _rc = (call); if (_rc) die("%s failed (%d): %s", #call, _rc, ocrgpu_last_error()); } while (0)
+
+static ocrgpu_engine_t *G;
+static int g_shutdown, g_exit_code, g_verbose;
+
+/* ---- guid pools: blocks of reserved guids per kind (guidReserve, ocr-guid.h:127-144) ------------------------ */
+enum { POOL_BLOCK = 4096 };
+typedef struct { u64 g[POOL_BLOCK]; u32 next, n; } Pool;
+static Pool pools[32];
+static u64 pool_take(u32 kind) {
+    Pool *p = &pools[kind];
+    if (p->next == p->n) { CHK(ocrgpu_guid_reserve(G, kind, POOL_BLOCK, p->g, OCRGPU_HOST)); p->next = 0; p->n = POOL_BLOCK; }
+    return p->g[p->next++];
+}
+
+/* ---- templates and tasks (host metadata: what ocrTaskTemplateHc_t / ocrTaskHc_t keep for taskExecute) ------- */
+typedef struct { ocrEdt_t fn; u32 paramc, depc; } Template;
+typedef struct {
+    ocrEdt_t fn; u32 paramc, depc; u64 *paramv;
+    u64 guid, outevt;
+    u64 scope_latch;   /* latch of the finish scope this EDT was created in (0 = none): DECR in its epilogue */
+    u64 own_latch;     /* EDT_PROP_FINISH: the latch of the scope it opens                                   */
+} Task;
+static Template *tpls; static size_t n_tpl, cap_tpl;
+static Task *tasks; static size_t n_task, cap_task;
+#define KIND_TEMPLATE 4u /* OCR_GUID_EDT_TEMPLATE (ocr-guid-kind.h:24); never enters the engine */
+static u64 tpl_guid(size_t i) { return ((u64)KIND_TEMPLATE << 49) | (u64)(i + 1); }
+
+/* ---- datablocks: payloads are host memory; guid -> {ptr} open-addressing map for ocrDbDestroy ---------------- */
+typedef struct { u64 guid; void *ptr; } DbEnt;
+static DbEnt *dbmap; static size_t dbmap_cap, dbmap_n;
+static size_t db_hash(u64 g) { return (size_t)((g * 0x9E3779B97F4A7C15ULL) >> 20); }
+static void dbmap_put(u64 g, void *p) {
+    if (2 * (dbmap_n + 1) > dbmap_cap) {
+        size_t oc = dbmap_cap; DbEnt *old = dbmap;
+        dbmap_cap = oc ? 2 * oc : 4096; dbmap = calloc(dbmap_cap, sizeof *dbmap); if (!dbmap) die("out of host memory");
+        dbmap_n = 0;
+        for (size_t i = 0; i < oc; ++i) if (old[i].guid && old[i].guid != ~0ULL) dbmap_put(old[i].guid, old[i].ptr);
+        free(old);
+    }
+    size_t h = db_hash(g) & (dbmap_cap - 1);
+    while (dbmap[h].guid && dbmap[h].guid != ~0ULL) h = (h + 1) & (dbmap_cap - 1);
+    dbmap[h].guid = g; dbmap[h].ptr = p; ++dbmap_n;
+}
+static void *dbmap_take(u64 g) {
+    if (!dbmap_cap) return NULL;
+    size_t h = db_hash(g) & (dbmap_cap - 1);
+    while (dbmap[h].guid) {
+        if (dbmap[h].guid == g) { void *p = dbmap[h].ptr; dbmap[h].guid = ~0ULL; dbmap[h].ptr = NULL; return p; }
+        h = (h + 1) & (dbmap_cap - 1);
+    }
+    return NULL;
+}
+
+/* ---- the deferred-op queue ---------------------------------------------------------------------------------- */
+enum { C_EVT_CREATE, C_DB_CREATE, C_EDT_CREATE, C_ADD_DEP, C_SATISFY, C_EVT_DESTROY, C_DB_DESTROY, N_CLASS };
+typedef struct { u8 cls, mode; u16 pad; u32 slot; u32 round; s32 arg; u64 a, b, c; u64 seq; } Op;
+static Op *ops; static size_t n_ops, cap_ops;
+/* per-body program-order state */
+static u32 cur_round; static int cur_cls;
+typedef struct { u64 evt; u32 slot; } Touched;
+static Touched *touched; static size_t n_touched, cap_touched;   /* events satisfied in the current round by this body */
+static Task *cur_task;            /* EDT whose body is running (NULL while mainEdt runs) */
+static u64 cur_scope;             /* latch of the finish scope children are created in   */
+static u32 pending_checkins;      /* children created in cur_scope by this body: INCRs issued when the body returns */
+
+static void body_begin(Task *t) {
+    cur_round = 0; cur_cls = -1; n_touched = 0; cur_task = t; pending_checkins = 0;
+    cur_scope = t ? (t->own_latch ? t->own_latch : t->scope_latch) : 0;
+}
+static Op *emit(int cls) {
+    if (cls < cur_cls) { ++cur_round; n_touched = 0; }
+    cur_cls = cls;
+    GROW(ops, n_ops, cap_ops);
+    Op *o = &ops[n_ops++];
+    memset(o, 0, sizeof *o);
+    o->cls = (u8)cls; o->round = cur_round; o->seq = n_ops;
+    return o;
+}
+static void emit_satisfy(u64 evt, u64 db, u32 slot) {
+    /* two satisfies of one event by one EDT keep their order unless they commute (same latch slot) */
+    const int latch = OCRGPU_GUID_KIND(evt) == OCRGPU_KIND_EVT_LATCH;
+    for (size_t i = 0; i < n_touched; ++i)
+        if (touched[i].evt == evt && !(latch && touched[i].slot == slot)) { ++cur_round; n_touched = 0; cur_cls = -1; break; }
+    Op *o = emit(C_SATISFY);
+    o->a = evt; o->b = db; o->slot = slot;
+    GROW(touched, n_touched, cap_touched);
+    touched[n_touched].evt = evt; touched[n_touched].slot = slot; ++n_touched;
+}
+/* taskEpilogue (hc-task.c:1707-1862): finish-scope check-ins of the children, output event, scope check-out */
+static void body_end(Task *t, u64 ret) {
+    for (u32 k = 0; k < pending_checkins; ++k) emit_satisfy(cur_scope, 0, OCRLATCH_INCR);
+    pending_checkins = 0;
+    if (!t) return;
+    if (t->own_latch) emit_satisfy(t->own_latch, 0, OCRLATCH_DECR);   /* the latch satisfies outevt and the outer scope */
+    else {
+        if (t->outevt) emit_satisfy(t->outevt, ret, 0);
+        if (t->scope_latch) emit_satisfy(t->scope_latch, 0, OCRLATCH_DECR);
+    }
+}
+
+static int op_cmp(const void *x, const void *y) {
+    const Op *a = x, *b = y;
+    if (a->round != b->round) return a->round < b->round ? -1 : 1;
+    if (a->cls != b->cls) return a->cls < b->cls ? -1 : 1;
+    return a->seq < b->seq ? -1 : (a->seq > b->seq ? 1 : 0); /* issue order */
+}
+
+static u64 *bu64[4]; static u32 *bu32[3]; static s32 *bs32; static size_t bcap;
+static void batch_room(size_t n) {
+    if (n <= bcap) return;
+    bcap = n + n / 2 + 64;
+    for (int i = 0; i < 4; ++i) bu64[i] = xrealloc(bu64[i], 8 * bcap);
+    for (int i = 0; i < 3; ++i) bu32[i] = xrealloc(bu32[i], 4 * bcap);
+    bs32 = xrealloc(bs32, 4 * bcap);
+}
+
+/* apply the queue: one C-ABI call per (round, class) */
+static void flush(void) {
+    if (!n_ops) return;
+    qsort(ops, n_ops, sizeof *ops, op_cmp);
+    size_t i = 0;
+    while (i < n_ops) {
+        size_t j = i;
+        while (j < n_ops && ops[j].round == ops[i].round && ops[j].cls == ops[i].cls) ++j;
+        const size_t n = j - i; const Op *o = ops + i;
+        batch_room(n);
+        switch (ops[i].cls) {
+        case C_EVT_CREATE:
+            for (size_t k = 0; k < n; ++k) { bu32[0][k] = o[k].slot; bs32[k] = o[k].arg; bu64[0][k] = o[k].a; }
+            CHK(ocrgpu_event_create(G, n, bu32[0], bs32, bu64[0], OCRGPU_HOST | OCRGPU_GUIDS_GIVEN));
+            break;
+        case C_DB_CREATE: /* value = host pointer, tag = guid: what ocrgpu_pop_ready hands back as depv */
+            for (size_t k = 0; k < n; ++k) { bu64[0][k] = o[k].b; bu64[1][k] = o[k].a; bu64[2][k] = o[k].a; }
+            CHK(ocrgpu_db_create(G, n, bu64[0], bu64[1], bu64[2], OCRGPU_HOST | OCRGPU_GUIDS_GIVEN));
+            break;
+        case C_EDT_CREATE:
+            for (size_t k = 0; k < n; ++k) {
+                bu32[0][k] = o[k].slot; bu32[1][k] = OCRBODY_HOST | (o[k].b ? OCRBODY_F_OUTEVT : 0u);
+                bu64[0][k] = o[k].c; bu64[1][k] = o[k].a; bu64[2][k] = o[k].b;
+            }
+            CHK(ocrgpu_edt_create(G, n, bu32[0], bu32[1], bu64[0], bu64[1], bu64[2], NULL, OCRGPU_HOST | OCRGPU_GUIDS_GIVEN));
+            break;
+        case C_ADD_DEP:
+            for (size_t k = 0; k < n; ++k) { bu64[0][k] = o[k].a; bu64[1][k] = o[k].b; bu32[0][k] = o[k].slot; bu32[1][k] = o[k].mode; }
+            CHK(ocrgpu_add_dependence(G, n, bu64[0], bu64[1], bu32[0], bu32[1], OCRGPU_HOST));
+            break;
+        case C_SATISFY:
+            for (size_t k = 0; k < n; ++k) { bu64[0][k] = o[k].a; bu64[1][k] = o[k].b; bu32[0][k] = o[k].slot; }
+            CHK(ocrgpu_event_satisfy_slot(G, n, bu64[0], bu64[1], bu32[0], OCRGPU_HOST));
+            break;
+        case C_EVT_DESTROY:
+            for (size_t k = 0; k < n; ++k) bu64[0][k] = o[k].a;
+            CHK(ocrgpu_event_destroy(G, n, bu64[0], OCRGPU_HOST));
+            break;
+        case C_DB_DESTROY:
+            for (size_t k = 0; k < n; ++k) { bu64[0][k] = o[k].a; free(dbmap_take(o[k].a)); }
+            CHK(ocrgpu_guid_remove(G, n, bu64[0], OCRGPU_HOST));
+            break;
+        }
+        i = j;
+    }
+    n_ops = 0;
+}
+
+/* ---- the OCR API -------------------------------------------------------------------------------------------- */
+static u32 evt_guid_kind(ocrEventTypes_t t) {
+    switch (t) {
+    case OCR_EVENT_ONCE_T: return OCRGPU_KIND_EVT_ONCE;
+    case OCR_EVENT_IDEM_T: return OCRGPU_KIND_EVT_IDEM;
+    case OCR_EVENT_STICKY_T: return OCRGPU_KIND_EVT_STICKY;
+    case OCR_EVENT_LATCH_T: return OCRGPU_KIND_EVT_LATCH;
+    default: return 0;
+    }
+}
+u8 ocrEventCreateParams(ocrGuid_t *guid, ocrEventTypes_t type, u16 properties, ocrEventParams_t *params) {
+    (void)properties;
+    u32 gk = evt_guid_kind(type);
+    if (!guid) return OCR_EINVAL;
+    if (!gk) { guid->guid = -1; return OCR_ENOTSUP; } /* COUNTED / CHANNEL: s8f item 3, not on the engine yet */
+    Op *o = emit(C_EVT_CREATE);
+    o->a = pool_take(gk); o->slot = (u32)type;
+    o->arg = (type == OCR_EVENT_LATCH_T && params) ? (s32)params->EVENT_LATCH.counter : 0; /* hc-event.c:1579-1589 */
+    guid->guid = (intptr_t)o->a;
+    return 0;
+}
+u8 ocrEventCreate(ocrGuid_t *guid, ocrEventTypes_t type, u16 properties) { return ocrEventCreateParams(guid, type, properties, NULL); }
+u8 ocrEventDestroy(ocrGuid_t guid) { Op *o = emit(C_EVT_DESTROY); o->a = (u64)guid.guid; return 0; }
+u8 ocrEventSatisfySlot(ocrGuid_t evt, ocrGuid_t db, u32 slot) {
+    if (ocrGuidIsNull(evt)) return 0; /* ocr-edt.c:171 */
+    emit_satisfy((u64)evt.guid, (u64)db.guid, slot);
+    return 0;
+}
+u8 ocrEventSatisfy(ocrGuid_t evt, ocrGuid_t db) { return ocrEventSatisfySlot(evt, db, 0); }
+u8 ocrAddDependence(ocrGuid_t src, ocrGuid_t dst, u32 slot, ocrDbAccessMode_t mode) {
+    Op *o = emit(C_ADD_DEP);
+    o->a = (u64)src.guid; o->b = (u64)dst.guid; o->slot = slot; o->mode = (u8)mode;
+    return 0;
+}
+
+u8 ocrDbCreate(ocrGuid_t *db, void **addr, u64 len, u16 flags, ocrHint_t *hint, ocrInDbAllocator_t allocator) {
+    (void)flags; (void)hint; (void)allocator;
+    if (!db || !addr) return OCR_EINVAL;
+    void *p = calloc(1, len ? len : 1);
+    if (!p) return OCR_ENOMEM;
+    Op *o = emit(C_DB_CREATE);
+    o->a = pool_take(OCRGPU_KIND_DB); o->b = (u64)(uintptr_t)p;
+    dbmap_put(o->a, p);
+    db->guid = (intptr_t)o->a; *addr = p;
+    return 0;
+}
+u8 ocrDbRelease(ocrGuid_t db) { (void)db; return 0; } /* payloads are plain host memory: nothing to write back */
+u8 ocrDbDestroy(ocrGuid_t db) { Op *o = emit(C_DB_DESTROY); o->a = (u64)db.guid; return 0; }
+
+u8 ocrEdtTemplateCreate_internal(ocrGuid_t *guid, ocrEdt_t fn, u32 paramc, u32 depc, const char *name) {
+    (void)name;
+    if (!guid || !fn) return OCR_EINVAL;
+    GROW(tpls, n_tpl, cap_tpl);
+    tpls[n_tpl].fn = fn; tpls[n_tpl].paramc = paramc; tpls[n_tpl].depc = depc;
+    guid->guid = (intptr_t)tpl_guid(n_tpl++);
+    return 0;
+}
+u8 ocrEdtTemplateDestroy(ocrGuid_t guid) { (void)guid; return 0; }
+u8 ocrEdtDestroy(ocrGuid_t guid) { (void)guid; return 0; }
+
+/* ocrEdtCreate (ocr-edt.c:295-523, hc-task.c:871-1136) */
+u8 ocrEdtCreate(ocrGuid_t *guid, ocrGuid_t tplGuid, u32 paramc, u64 *paramv, u32 depc, ocrGuid_t *depv, u16 props,
+                ocrHint_t *hint, ocrGuid_t *outputEvent) {
+    (void)hint;
+    u64 tg = (u64)tplGuid.guid;
+    if (OCRGPU_GUID_KIND(tg) != KIND_TEMPLATE || (tg & 0xFFFFFFFFu) == 0 || (tg & 0xFFFFFFFFu) > n_tpl) return OCR_EINVAL;
+    const Template *tp = &tpls[(tg & 0xFFFFFFFFu) - 1];
+    if (paramc == EDT_PARAM_DEF) paramc = tp->paramc;
+    if (depc == EDT_PARAM_DEF) depc = tp->depc;
+    if (paramc == EDT_PARAM_UNK || depc == EDT_PARAM_UNK) return OCR_EINVAL;            /* ocr-edt.c:330-360 */
+    if ((tp->paramc != EDT_PARAM_UNK && tp->paramc != paramc) || (tp->depc != EDT_PARAM_UNK && tp->depc != depc)) return OCR_EINVAL;
+    if (paramc && !paramv) return OCR_EINVAL;
+    const int finish = (props & EDT_PROP_FINISH) != 0;
+    const int want_out = outputEvent != NULL || finish;
+
+    GROW(tasks, n_task, cap_task);
+    const size_t ti = n_task++;
+    Task *t = &tasks[ti];
+    memset(t, 0, sizeof *t);
+    t->fn = tp->fn; t->paramc = paramc; t->depc = depc;
+    if (paramc) { t->paramv = xrealloc(NULL, 8 * (size_t)paramc); memcpy(t->paramv, paramv, 8 * (size_t)paramc); }
+    t->guid = pool_take(OCRGPU_KIND_EDT);
+    t->outevt = want_out ? pool_take(OCRGPU_KIND_EVT_ONCE) : 0;
+    t->scope_latch = cur_scope;
+    if (finish) { /* the scope's latch starts at 1: the finish EDT itself (hc-task.c:1931-1933) */
+        t->own_latch = pool_take(OCRGPU_KIND_EVT_LATCH);
+        Op *l = emit(C_EVT_CREATE); l->a = t->own_latch; l->slot = OCREVT_LATCH; l->arg = 1;
+    }
+    Op *o = emit(C_EDT_CREATE);
+    o->a = t->guid; o->b = t->outevt; o->c = (u64)ti; o->slot = depc;
+    if (finish) {
+        Op *d = emit(C_ADD_DEP); d->a = t->own_latch; d->b = t->outevt; d->slot = 0; d->mode = DB_MODE_RW;
+        if (t->scope_latch) { d = emit(C_ADD_DEP); d->a = t->own_latch; d->b = t->scope_latch; d->slot = OCRLATCH_DECR; d->mode = DB_MODE_RW; }
+    }
+    if (depv) /* hc-policy.c:2262-2320: UNINITIALIZED_GUID entries are left for a later ocrAddDependence */
+        for (u32 k = 0; k < depc; ++k)
+            if (!ocrGuidIsUninitialized(depv[k])) { Op *d = emit(C_ADD_DEP); d->a = (u64)depv[k].guid; d->b = t->guid; d->slot = k; d->mode = DB_DEFAULT_MODE; }
+    if (t->scope_latch) ++pending_checkins; /* hc-task.c:1071-1078 */
+    if (guid) guid->guid = (intptr_t)t->guid;
+    if (outputEvent) outputEvent->guid = (intptr_t)t->outevt;
+    return 0;
+}
+
+void ocrShutdown(void) { g_shutdown = 1; }
+void ocrAbort(u8 code) { g_shutdown = 1; g_exit_code = code; }
+u64 getArgc(void *dbPtr) { return ((u64 *)dbPtr)[0]; }                                  /* ocr.c:94-100 */
+char *getArgv(void *dbPtr, u64 count) { return (char *)dbPtr + ((u64 *)dbPtr)[1 + count]; } /* ocr.c:102-110 */
+u32 PRINTF(const char *fmt, ...) { va_list ap; va_start(ap, fmt); int n = vprintf(fmt, ap); va_end(ap); fflush(stdout); return n < 0 ? 0u : (u32)n; }
+u32 SNPRINTF(char *buf, u32 size, const char *fmt, ...) { va_list ap; va_start(ap, fmt); int n = vsnprintf(buf, size, fmt, ap); va_end(ap); return n < 0 ? 0u : (u32)n; }
+void _ocrAssert(bool val, const char *str, const char *file, u32 line) {
+    if (val) return;
+    fprintf(stderr, "ASSERT: %s @ %s:%u\n", str, file, line); fflush(stderr);
+    abort();
+}
+
+/* ---- driver ---------------------------------------------------------------------------------------------------- */
+static u64 env_u64(const char *name, u64 dflt) { const char *v = getenv(name); return v && *v ? strtoull(v, NULL, 0) : dflt; }
+
+/* packUserArguments (ocr-driver.c:1034, read back by getArgc/getArgv): u64 argc, u64 offset[argc], the strings */
+static void *pack_args(int argc, char **argv, u64 *len_out) {
+    u64 len = 8 * (u64)(1 + argc);
+    for (int i = 0; i < argc; ++i) len += strlen(argv[i]) + 1;
+    char *p = calloc(1, len); if (!p) die("out of host memory");
+    u64 off = 8 * (u64)(1 + argc);
+    ((u64 *)p)[0] = (u64)argc;
+    for (int i = 0; i < argc; ++i) { ((u64 *)p)[1 + i] = off; strcpy(p + off, argv[i]); off += strlen(argv[i]) + 1; }
+    *len_out = len;
+    return p;
+}
+
+int ocrshim_run(int argc, char **argv) {
+    /* -ocr:cfg <file> is accepted and ignored: capacities come from the environment */
+    int uargc = 0; char **uargv = calloc((size_t)argc + 1, sizeof *uargv);
+    for (int i = 0; i < argc; ++i) {
+        if (!strncmp(argv[i], "-ocr:", 5)) { if (i + 1 < argc && strcmp(argv[i], "-ocr:version")) ++i; continue; }
+        uargv[uargc++] = argv[i];
+    }
+    g_verbose = (int)env_u64("OCRSHIM_VERBOSE", 0);
+    ocrgpu_config_t cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.max_edt = (u32)env_u64("OCRSHIM_MAX_EDT", 1u << 20);
+    cfg.max_evt = (u32)env_u64("OCRSHIM_MAX_EVT", 1u << 20);
+    cfg.max_db = (u32)env_u64("OCRSHIM_MAX_DB", 1u << 20);
+    cfg.max_slots = env_u64("OCRSHIM_MAX_SLOTS", 1u << 22);
+    cfg.max_edges = env_u64("OCRSHIM_MAX_EDGES", 1u << 23);
+    cfg.location = 0;
+    cfg.flags = env_u64("OCRSHIM_NANNY", 1) ? OCRGPU_F_NANNY : 0; /* user programs: report double satisfies (hc-task.c:1243) */
+    int rc = ocrgpu_init(&G, (int)env_u64("OCRSHIM_DEVICE", 0), &cfg);
+    if (rc) { fprintf(stderr, "ocrshim: ocrgpu_init failed (%d): %s\n", rc, ocrgpu_last_error()); return 71; }
+
+    /* mainEdt(paramc 0, depc 1: the argument datablock), ocr-driver.c:1034-1060 */
+    u64 alen; void *args = pack_args(uargc, uargv, &alen);
+    body_begin(NULL);
+    ocrGuid_t adb; void *aptr;
+    ocrDbCreate(&adb, &aptr, alen, DB_PROP_NONE, NULL_HINT, NO_ALLOC);
+    memcpy(aptr, args, alen); free(args);
+    ocrEdtDep_t mdep = { adb, aptr, DB_MODE_RW };
+    mainEdt(0, NULL, 1, &mdep);
+    body_end(NULL, 0);
+
+    size_t cap_e = 1024, cap_d = 4096;
+    u64 *p0 = xrealloc(NULL, 8 * cap_e), *dg = xrealloc(NULL, 8 * cap_d), *dv = xrealloc(NULL, 8 * cap_d);
+    u32 *dc = xrealloc(NULL, 4 * cap_e), *df = xrealloc(NULL, 4 * cap_e);
+    ocrEdtDep_t *depv = NULL; size_t cap_depv = 0;
+    u64 levels = 0, bodies = 0;
+    while (!g_shutdown) {
+        flush();
+        u64 has_ready = 0, pending = 0;
+        CHK(ocrgpu_step(G, 1, 0, &has_ready, &pending, NULL));
+        ++levels;
+        u64 ne = 0, nd = 0;
+        for (;;) {
+            rc = ocrgpu_pop_ready(G, cap_e, cap_d, &ne, &nd, p0, dc, df, dg, dv);
+            if (rc == OCRGPU_ENOMEM && (ne > cap_e || nd > cap_d)) {
+                if (ne > cap_e) { cap_e = ne + ne / 2; p0 = xrealloc(p0, 8 * cap_e); dc = xrealloc(dc, 4 * cap_e); df = xrealloc(df, 4 * cap_e); }
+                if (nd > cap_d) { cap_d = nd + nd / 2; dg = xrealloc(dg, 8 * cap_d); dv = xrealloc(dv, 8 * cap_d); }
+                continue;
+            }
+            if (rc) die("ocrgpu_pop_ready failed (%d): %s", rc, ocrgpu_last_error());
+            break;
+        }
+        if (ne == 0) {
+            if (has_ready) continue; /* built-in bodies only on this level */
+            fprintf(stderr, "ocrshim: no runnable EDT left and ocrShutdown() was not called (%llu EDTs ran)\n", (unsigned long long)bodies);
+            g_exit_code = 72;
+            break;
+        }
+        for (u64 i = 0; i < ne && !g_shutdown; ++i) {
+            if (p0[i] >= n_task) die("engine returned an unknown task handle");
+            /* the task array may move while the body creates EDTs: work on a copy */
+            Task t = tasks[p0[i]];
+            if (dc[i] != t.depc) die("depc mismatch for task %llu", (unsigned long long)p0[i]);
+            if (t.depc > cap_depv) { cap_depv = t.depc + 16; depv = xrealloc(depv, cap_depv * sizeof *depv); }
+            for (u32 k = 0; k < t.depc; ++k) {
+                depv[k].guid.guid = (intptr_t)dg[df[i] + k]; depv[k].ptr = (void *)(uintptr_t)dv[df[i] + k]; depv[k].mode = DB_DEFAULT_MODE;
+            }
+            body_begin(&t);
+            ocrGuid_t ret = t.fn(t.paramc, t.paramv, t.depc, depv);
+            body_end(&t, (u64)ret.guid);
+            free(tasks[p0[i]].paramv); tasks[p0[i]].paramv = NULL;
+            ++bodies;
+        }
+    }
+    ocrgpu_stats_t st; memset(&st, 0, sizeof st);
+    CHK(ocrgpu_get_stats(G, &st));
+    u64 errs = 0; for (int i = 0; i < 8; ++i) errs += st.err[i];
+    if (g_verbose || errs)
+        fprintf(stderr, "ocrshim: levels=%llu bodies=%llu edt_sat=%llu evt_sat=%llu err=[%llu %llu %llu %llu %llu %llu %llu]\n",
+                (unsigned long long)levels, (unsigned long long)bodies, (unsigned long long)st.edt_sat, (unsigned long long)st.evt_sat,
+                (unsigned long long)st.err[0], (unsigned long long)st.err[1], (unsigned long long)st.err[2], (unsigned long long)st.err[3],
+                (unsigned long long)st.err[4], (unsigned long long)st.err[5], (unsigned long long)st.err[6]);
+    if (errs && !g_exit_code) g_exit_code = 73;
+    ocrgpu_fini(G);
+    return g_exit_code;
+}
+
+/* libocr provides main() and calls the program's mainEdt (ocr-driver.c:1000-1060); so does the shim */
+__attribute__((weak)) int main(int argc, char **argv) { return ocrshim_run(argc, argv); }
