@@ -63,6 +63,7 @@ typedef struct {
     u64 guid, outevt;
     u64 scope_latch;   /* latch of the finish scope this EDT was created in (0 = none): DECR in its epilogue */
     u64 own_latch;     /* EDT_PROP_FINISH: the latch of the scope it opens                                   */
+    u8 ran, destroyed;
 } Task;
 static Template *tpls; static size_t n_tpl, cap_tpl;
 static Task *tasks; static size_t n_task, cap_task;
@@ -106,9 +107,10 @@ static Touched *touched; static size_t n_touched, cap_touched;   /* events satis
 static Task *cur_task;            /* EDT whose body is running (NULL while mainEdt runs) */
 static u64 cur_scope;             /* latch of the finish scope children are created in   */
 static u32 pending_checkins;      /* children created in cur_scope by this body: INCRs issued when the body returns */
+static size_t body_first_task;    /* tasks[body_first_task..] were created by the running body */
 
 static void body_begin(Task *t) {
-    cur_round = 0; cur_cls = -1; n_touched = 0; cur_task = t; pending_checkins = 0;
+    cur_round = 0; cur_cls = -1; n_touched = 0; cur_task = t; pending_checkins = 0; body_first_task = n_task;
     cur_scope = t ? (t->own_latch ? t->own_latch : t->scope_latch) : 0;
 }
 static Op *emit(int cls) {
@@ -130,16 +132,17 @@ static void emit_satisfy(u64 evt, u64 db, u32 slot) {
     GROW(touched, n_touched, cap_touched);
     touched[n_touched].evt = evt; touched[n_touched].slot = slot; ++n_touched;
 }
-/* taskEpilogue (hc-task.c:1707-1862): finish-scope check-ins of the children, output event, scope check-out */
+/* taskEpilogue (hc-task.c:1784-1831): the returned guid goes to the output event through an add-dependence (a DB or
+ * NULL_GUID satisfies it, an EVENT is chained to it); the finish scope this EDT opened, or else the one it lives in,
+ * is checked out; a finish EDT's latch takes care of its output event.  The check-ins of the children created by
+ * this body (hc-task.c:1071-1078) are issued here, before the check-out. */
 static void body_end(Task *t, u64 ret) {
+    if (t && !t->own_latch && t->outevt) { Op *d = emit(C_ADD_DEP); d->a = ret; d->b = t->outevt; d->slot = 0; d->mode = DB_MODE_RW; }
     for (u32 k = 0; k < pending_checkins; ++k) emit_satisfy(cur_scope, 0, OCRLATCH_INCR);
     pending_checkins = 0;
     if (!t) return;
-    if (t->own_latch) emit_satisfy(t->own_latch, 0, OCRLATCH_DECR);   /* the latch satisfies outevt and the outer scope */
-    else {
-        if (t->outevt) emit_satisfy(t->outevt, ret, 0);
-        if (t->scope_latch) emit_satisfy(t->scope_latch, 0, OCRLATCH_DECR);
-    }
+    if (t->own_latch) emit_satisfy(t->own_latch, ret, OCRLATCH_DECR);
+    else if (t->scope_latch) emit_satisfy(t->scope_latch, 0, OCRLATCH_DECR);
 }
 
 static int op_cmp(const void *x, const void *y) {
@@ -242,14 +245,14 @@ u8 ocrAddDependence(ocrGuid_t src, ocrGuid_t dst, u32 slot, ocrDbAccessMode_t mo
 }
 
 u8 ocrDbCreate(ocrGuid_t *db, void **addr, u64 len, u16 flags, ocrHint_t *hint, ocrInDbAllocator_t allocator) {
-    (void)flags; (void)hint; (void)allocator;
+    (void)hint; (void)allocator;
     if (!db || !addr) return OCR_EINVAL;
     void *p = calloc(1, len ? len : 1);
     if (!p) return OCR_ENOMEM;
     Op *o = emit(C_DB_CREATE);
     o->a = pool_take(OCRGPU_KIND_DB); o->b = (u64)(uintptr_t)p;
     dbmap_put(o->a, p);
-    db->guid = (intptr_t)o->a; *addr = p;
+    db->guid = (intptr_t)o->a; *addr = (flags & DB_PROP_NO_ACQUIRE) ? NULL : p; /* ocr-db.h:60-64 */
     return 0;
 }
 u8 ocrDbRelease(ocrGuid_t db) { (void)db; return 0; } /* payloads are plain host memory: nothing to write back */
@@ -264,7 +267,21 @@ u8 ocrEdtTemplateCreate_internal(ocrGuid_t *guid, ocrEdt_t fn, u32 paramc, u32 d
     return 0;
 }
 u8 ocrEdtTemplateDestroy(ocrGuid_t guid) { (void)guid; return 0; }
-u8 ocrEdtDestroy(ocrGuid_t guid) { (void)guid; return 0; }
+/* ocrEdtDestroy of an EDT that has not run (destructTaskHc, hc-task.c:760-790): it leaves its finish scope */
+u8 ocrEdtDestroy(ocrGuid_t guid) {
+    for (size_t i = n_task; i-- > 0;) {
+        Task *t = &tasks[i];
+        if (t->guid != (u64)guid.guid) continue;
+        if (t->ran || t->destroyed) return 0;
+        t->destroyed = 1;
+        if (t->scope_latch) {
+            if (i >= body_first_task && pending_checkins) --pending_checkins; /* its check-in has not been issued yet */
+            else emit_satisfy(t->scope_latch, 0, OCRLATCH_DECR);
+        }
+        return 0;
+    }
+    return OCR_EINVAL;
+}
 
 /* ocrEdtCreate (ocr-edt.c:295-523, hc-task.c:871-1136) */
 u8 ocrEdtCreate(ocrGuid_t *guid, ocrGuid_t tplGuid, u32 paramc, u64 *paramv, u32 depc, ocrGuid_t *depv, u16 props,
@@ -277,7 +294,7 @@ u8 ocrEdtCreate(ocrGuid_t *guid, ocrGuid_t tplGuid, u32 paramc, u64 *paramv, u32
     if (depc == EDT_PARAM_DEF) depc = tp->depc;
     if (paramc == EDT_PARAM_UNK || depc == EDT_PARAM_UNK) return OCR_EINVAL;            /* ocr-edt.c:330-360 */
     if ((tp->paramc != EDT_PARAM_UNK && tp->paramc != paramc) || (tp->depc != EDT_PARAM_UNK && tp->depc != depc)) return OCR_EINVAL;
-    if (paramc && !paramv) return OCR_EINVAL;
+    if ((paramc && !paramv) || (!paramc && paramv)) return OCR_EINVAL;                       /* hc-policy.c:846-855 */
     const int finish = (props & EDT_PROP_FINISH) != 0;
     const int want_out = outputEvent != NULL || finish;
 
@@ -396,6 +413,8 @@ int ocrshim_run(int argc, char **argv) {
             if (p0[i] >= n_task) die("engine returned an unknown task handle");
             /* the task array may move while the body creates EDTs: work on a copy */
             Task t = tasks[p0[i]];
+            if (t.destroyed) continue;
+            tasks[p0[i]].ran = 1;
             if (dc[i] != t.depc) die("depc mismatch for task %llu", (unsigned long long)p0[i]);
             if (t.depc > cap_depv) { cap_depv = t.depc + 16; depv = xrealloc(depv, cap_depv * sizeof *depv); }
             for (u32 k = 0; k < t.depc; ++k) {
