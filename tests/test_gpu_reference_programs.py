@@ -37,7 +37,10 @@ def test_reference_program(name):
 
 def test_fib20():
     """BASELINE config 1 on the engine: same program text as oracle/_ref/ocr_fib_dbg (6765, 21891 + 10945 EDTs)."""
-    exe = os.path.join(ROOT, "ocr_amd", "bin", "fib")
+    import sys
+    sys.path.insert(0, ROOT)
+    from ocr_amd import build as B
+    exe = B.build_program(os.path.join(ROOT, "tests", "programs", "fib.c"))   # no-op when ocr_amd/bin/fib is up to date
     r = subprocess.run([exe, "20"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert r.stdout.strip() == "FIB n=20 result=6765 fib_edts=21891 sum_edts=10945"
