@@ -89,6 +89,7 @@ typedef struct {
 #define EDT_PROP_FINISH ((u16)0x1)
 #define EDT_PROP_NO_HINT ((u16)0x2)
 #define EDT_PROP_LONG ((u16)0x4)
+#define EDT_PROP_OEVT_VALID ((u16)0x8) /* *outputEvent names an existing event the EDT's epilogue satisfies */
 #define EDT_PARAM_UNK ((u32)-1)
 #define EDT_PARAM_DEF ((u32)-2)
 typedef ocrGuid_t (*ocrEdt_t)(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]);

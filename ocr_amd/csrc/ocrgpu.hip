@@ -213,6 +213,28 @@ __device__ __forceinline__ bool evt_satisfy_simple(const Dev &d, u32 x, u32 kind
         if ((old & 0xFF) != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u); return false; }
         return true;
     }
+    if (kind == OCREVT_COUNTED) {
+        // satisfyEventHcCounted (hc-event.c:537-565): sticky; nbDeps (bits 16..31 of the state word) drops by the
+        // waiters registered so far -- the row length, exact here because the CSR is sealed before any k_step --
+        // and the event is gone once all nbDeps registrations have been served.
+        const u32 deg = *evt_deg(d, x);
+        u32 old = *sk;
+        for (;;) {
+            if ((old & 0xFF) != ST_LIVE) {
+                atomicAdd(&d.ctrl->err[(old & 0xFF) == ST_SAT ? ERR_STICKY_RESAT : ERR_DEAD_EVENT], 1u);
+                return false;
+            }
+            const u32 cnt = old >> 16;
+            if (deg > cnt) atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); // more registrations than nbDeps (assert :553)
+            const u32 left = cnt > deg ? cnt - deg : 0u;
+            const u32 nw = (left ? (u32)ST_SAT : (u32)ST_DESTROYED) | (kind << 8) | (left << 16);
+            const u32 prev = atomicCAS(sk, old, nw);
+            if (prev == old) break;
+            old = prev;
+        }
+        *evt_val(d, x) = (s32)payload;
+        return true;
+    }
     u32 old = atomicCAS(sk, ST_LIVE | (kind << 8), ST_SAT | (kind << 8));
     if ((old & 0xFF) == ST_LIVE) { *evt_val(d, x) = (s32)payload; return true; }
     if ((old & 0xFF) == ST_SAT) { if (kind == OCREVT_STICKY) atomicAdd(&d.ctrl->err[ERR_STICKY_RESAT], 1u); }
@@ -318,7 +340,7 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         if (__ballot(to_evt)) {
             bool fire = latch_group(d, is_latch, dst, slot);
             if (to_evt && !is_latch) {
-                if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM) fire = evt_satisfy_simple(d, dst, kind, payload);
+                if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM || kind == OCREVT_COUNTED) fire = evt_satisfy_simple(d, dst, kind, payload);
                 else atomicAdd(&c->err[ERR_DEAD_EVENT], 1u);
             }
             bool toq = fire && *evt_deg(d, dst) != 0;
@@ -530,7 +552,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             bool fire = latch_group(d, is_latch, r.dst, r.slot);
             if (act && (r.flags & RF_FIRED)) fire = true;
             else if (act && !(r.flags & RF_DST_EDT) && !is_latch) {
-                if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM) fire = evt_satisfy_simple(d, r.dst, kind, r.payload);
+                if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM || kind == OCREVT_COUNTED) fire = evt_satisfy_simple(d, r.dst, kind, r.payload);
                 else atomicAdd(&c->err[(*evt_state(d, r.dst) & 0xFF) == ST_ABSENT ? ERR_BAD_OP : ERR_DEAD_EVENT], 1u);
             }
             if (fire) {
@@ -601,7 +623,12 @@ __global__ void k_event_create(Dev d, u64 n, const u32 *kind, const s32 *arg, u3
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 k = kind[i], x = first_idx + (u32)i;
-    d.evt[x] = EvtRec{0, 0, ST_LIVE | (k << 8), k == OCREVT_LATCH ? arg[i] : 0};
+    u32 hi = 0;
+    if (k == OCREVT_COUNTED) { // nbDeps rides in bits 16..31 of the state word (hc-event.c:1600-1612: nbDeps > 0)
+        if (arg[i] <= 0 || arg[i] > 0xFFFF) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return; }
+        hi = (u32)arg[i] << 16;
+    } else if (k < OCREVT_ONCE || k > OCREVT_LATCH) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return; } // CHANNEL: not on the engine
+    d.evt[x] = EvtRec{0, 0, ST_LIVE | (k << 8) | hi, k == OCREVT_LATCH ? arg[i] : 0};
     u64 g = gin ? gin[i] : mkguid(d.location, evt_kind_to_guid_kind(k), first_counter + i);
     if (gin && !given_ok(d, g, evt_kind_to_guid_kind(k))) return;
     gtab_put(d, g, (u64)x + 1);
@@ -680,6 +707,15 @@ __device__ bool resolve_dst(const Dev &d, u64 g, u32 slot, u32 &idx, u32 &flags,
     flags = 0; slot_out = slot; return slot < (1u << 28);
 }
 
+// registerWaiterEventHcCounted on a satisfied event (hc-event.c:1211-1238): the registration is counted, the last one
+// destroys the event
+__device__ __forceinline__ void counted_late_registration(const Dev &d, u32 x) {
+    u32 *sk = evt_state(d, x);
+    if (((*sk >> 8) & 0xFF) != OCREVT_COUNTED) return;
+    u32 o = atomicSub(sk, 1u << 16);
+    if ((o >> 16) == 1u) atomicExch(sk, (u32)ST_DESTROYED | (OCREVT_COUNTED << 8));
+}
+
 // ocrAddDependence classification (hc-policy.c:2857-3074)
 __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode, u32 nanny) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -700,7 +736,7 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
         if (sk == OCRGPU_KIND_DB) { emit_remote(d, dg, slot[i], xf, (u32)sv); return; }
         if (!is_event_kind(sk)) { bad_op(d); return; }
         u32 x = (u32)(sv - 1), st = *evt_state(d, x) & 0xFF;
-        if (st == ST_SAT) { emit_remote(d, dg, slot[i], xf, (u32)*evt_val(d, x)); return; }
+        if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); counted_late_registration(d, x); emit_remote(d, dg, slot[i], xf, pv); return; }
         if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }
         u32 ri = atomicAdd(&d.ctrl->rdst_tail, 1u), li = atomicAdd(&d.ctrl->log_tail, 1u);
         if (ri >= d.rdst_cap || li >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
@@ -720,7 +756,7 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
     if (!is_event_kind(sk)) { bad_op(d); return; }
     u32 x = (u32)(sv - 1);
     u32 st = *evt_state(d, x) & 0xFF;
-    if (st == ST_SAT) { q_push(d, Rec{didx, (u32)*evt_val(d, x), dslot, dflag | mnull}); return; } // registerWaiterEventHcPersist :1143-1155
+    if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); counted_late_registration(d, x); q_push(d, Rec{didx, pv, dslot, dflag | mnull}); return; } // registerWaiterEventHcPersist :1143-1155
     if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }    // registerWaiterEventHc :1078-1083
     // Payload pre-resolution: when what this dependence will deliver is already known -- nothing (DB_MODE_NULL),
     // or the output DB / NULL_GUID of a built-in HASH / NOP body behind an output event -- write the pre-slot word

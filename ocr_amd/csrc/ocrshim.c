@@ -216,6 +216,7 @@ static u32 evt_guid_kind(ocrEventTypes_t t) {
     case OCR_EVENT_IDEM_T: return OCRGPU_KIND_EVT_IDEM;
     case OCR_EVENT_STICKY_T: return OCRGPU_KIND_EVT_STICKY;
     case OCR_EVENT_LATCH_T: return OCRGPU_KIND_EVT_LATCH;
+    case OCR_EVENT_COUNTED_T: return OCRGPU_KIND_EVT_COUNTED;
     default: return 0;
     }
 }
@@ -223,10 +224,12 @@ u8 ocrEventCreateParams(ocrGuid_t *guid, ocrEventTypes_t type, u16 properties, o
     (void)properties;
     u32 gk = evt_guid_kind(type);
     if (!guid) return OCR_EINVAL;
-    if (!gk) { guid->guid = -1; return OCR_ENOTSUP; } /* COUNTED / CHANNEL: s8f item 3, not on the engine yet */
+    if (!gk) { guid->guid = -1; return OCR_ENOTSUP; } /* CHANNEL: s8f item 3, not on the engine yet */
+    if (type == OCR_EVENT_COUNTED_T && (!params || params->EVENT_COUNTED.nbDeps == 0 || params->EVENT_COUNTED.nbDeps > 0xFFFF)) { guid->guid = -1; return OCR_EINVAL; }
     Op *o = emit(C_EVT_CREATE);
     o->a = pool_take(gk); o->slot = (u32)type;
-    o->arg = (type == OCR_EVENT_LATCH_T && params) ? (s32)params->EVENT_LATCH.counter : 0; /* hc-event.c:1579-1589 */
+    o->arg = (type == OCR_EVENT_LATCH_T && params) ? (s32)params->EVENT_LATCH.counter        /* hc-event.c:1579-1589 */
+           : type == OCR_EVENT_COUNTED_T ? (s32)params->EVENT_COUNTED.nbDeps : 0;            /* hc-event.c:1600-1612 */
     guid->guid = (intptr_t)o->a;
     return 0;
 }
@@ -305,14 +308,17 @@ u8 ocrEdtCreate(ocrGuid_t *guid, ocrGuid_t tplGuid, u32 paramc, u64 *paramv, u32
     t->fn = tp->fn; t->paramc = paramc; t->depc = depc;
     if (paramc) { t->paramv = xrealloc(NULL, 8 * (size_t)paramc); memcpy(t->paramv, paramv, 8 * (size_t)paramc); }
     t->guid = pool_take(OCRGPU_KIND_EDT);
-    t->outevt = want_out ? pool_take(OCRGPU_KIND_EVT_ONCE) : 0;
+    /* EDT_PROP_OEVT_VALID (ocr-edt.c:378-386, hc-task.c:940-959): the caller's own event takes the place of the ONCE */
+    const int own_evt = (props & EDT_PROP_OEVT_VALID) && outputEvent && outputEvent->guid != 0 && outputEvent->guid != -1 && outputEvent->guid != -2;
+    if ((props & EDT_PROP_OEVT_VALID) && !own_evt) { --n_task; return OCR_EINVAL; }
+    t->outevt = own_evt ? (u64)outputEvent->guid : want_out ? pool_take(OCRGPU_KIND_EVT_ONCE) : 0;
     t->scope_latch = cur_scope;
     if (finish) { /* the scope's latch starts at 1: the finish EDT itself (hc-task.c:1931-1933) */
         t->own_latch = pool_take(OCRGPU_KIND_EVT_LATCH);
         Op *l = emit(C_EVT_CREATE); l->a = t->own_latch; l->slot = OCREVT_LATCH; l->arg = 1;
     }
     Op *o = emit(C_EDT_CREATE);
-    o->a = t->guid; o->b = t->outevt; o->c = (u64)ti; o->slot = depc;
+    o->a = t->guid; o->b = own_evt ? 0 : t->outevt; o->c = (u64)ti; o->slot = depc;
     if (finish) {
         Op *d = emit(C_ADD_DEP); d->a = t->own_latch; d->b = t->outevt; d->slot = 0; d->mode = DB_MODE_RW;
         if (t->scope_latch) { d = emit(C_ADD_DEP); d->a = t->own_latch; d->b = t->scope_latch; d->slot = OCRLATCH_DECR; d->mode = DB_MODE_RW; }

@@ -179,8 +179,6 @@ class Partition:
                     eng.add_dependence(self._guids(b["a"]), self._guids(b["b"]), b["slot"], b["mode"].astype(np.uint32))
                 yield op
             elif op == ops.OP_SATISFY:
-                if not scripts_done and self._scripted_edts_exist():
-                    self._set_scripts(); scripts_done = True
                 for c0, c1 in ops.split_conflicts(blk["a"]):   # two satisfies of one event keep program order
                     sub = blk[c0:c1]
                     po, eo = self._owner_of_refs(sub["b"]), self._owner_of_refs(sub["a"])

@@ -349,7 +349,6 @@ class StreamProgram:
             elif op == ops.OP_ADD_DEP:
                 eng.add_dependence(self._guids(blk["a"]), self._guids(blk["b"]), blk["slot"], blk["mode"].astype(np.uint32))
             elif op == ops.OP_SATISFY:
-                self._set_scripts()
                 for c0, c1 in ops.split_conflicts(blk["a"]):   # two satisfies of one event keep program order
                     b = blk[c0:c1]
                     eng.event_satisfy_slot(self._guids(b["a"]), self._guids(b["b"]), b["slot"])
@@ -357,7 +356,7 @@ class StreamProgram:
                 eng.event_destroy(self._guids(blk["a"]))
             else:
                 raise ValueError(f"bad op {op}")
-        self._set_scripts()
+        self._set_scripts()   # bodies only run in resolve(): by now every event a script names exists
         self._built = True
         return self
 

@@ -112,6 +112,13 @@ static void drain(eng_t *E) {
         case OCREVT_IDEM: case OCREVT_STICKY:
             if (v->state == ST_SAT) { if (v->kind == OCREVT_STICKY) E->err[ERR_STICKY_RESAT]++; break; }
             v->data = w.payload; v->state = ST_SAT; fan_out(E, v, w.payload); break;
+        case OCREVT_COUNTED: /* satisfyEventHcCounted hc-event.c:537-565: sticky, and gone once nbDeps waiters were served */
+            if (v->state == ST_SAT) { E->err[ERR_STICKY_RESAT]++; break; }
+            v->data = w.payload; v->state = ST_SAT;
+            v->counter -= (int32_t)v->n_w;                 /* nbDeps -= waitersCount (:556) */
+            fan_out(E, v, w.payload);
+            if (v->counter == 0) v->state = ST_DESTROYED;  /* :557,561 */
+            break;
         default: E->err[ERR_BAD_OP]++; break;
         }
     }
@@ -140,6 +147,8 @@ static void op_add_dep(eng_t *E, const ocrops_op_t *op) {
     if (v->state == ST_DESTROYED || v->state == ST_ABSENT) { E->err[ERR_ONCE_LATE_WAITER]++; return; }
     if (v->state == ST_SAT) { /* persistent, already satisfied: immediate satisfy with stored data */
         work_t w = { dst, op->slot, v->data, (uint8_t)dst_is_evt, mode_null };
+        /* registerWaiterEventHcCounted hc-event.c:1211-1238: the late registration is counted; the last one destroys */
+        if (v->kind == OCREVT_COUNTED && --v->counter == 0) v->state = ST_DESTROYED;
         push_work(E, w); drain(E);
         return;
     }
@@ -211,7 +220,7 @@ int ocrref_run(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_
         const ocrops_op_t *op = &main_ops[k];
         switch (op->op) {
         case OCROP_EVT_CREATE: { event_t *v = &E.ev[op->a]; v->kind = evt[op->a].kind; v->state = ST_LIVE;
-                                  v->counter = (v->kind == OCREVT_LATCH) ? evt[op->a].arg : 0; } break;
+                                  v->counter = (v->kind == OCREVT_LATCH || v->kind == OCREVT_COUNTED) ? evt[op->a].arg : 0; } break;
         case OCROP_DB_CREATE: E.db_val[op->a] = db_init[op->a]; E.db_live[op->a] = 1; break;
         case OCROP_EDT_CREATE: { uint32_t e = (uint32_t)op->a; E.ed[e].created = 1;
                                   if (edt[e].body & OCRBODY_F_OUTEVT) { event_t *v = &E.ev[h->n_evt + e]; v->kind = OCREVT_ONCE; v->state = ST_LIVE; }

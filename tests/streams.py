@@ -6,7 +6,7 @@ testOcrEventToEventDeps0.c, testOcrAddDeps*.c, testOcrDepv*.c, testOcrOutputEven
 testOcrEventParam*.c, dist/testDuplicateDeps*.c) as data, so all three executors can run them.
 Every stream is well formed: its outcome does not depend on the schedule.
 """
-from ocr_amd.opstream import (BODY_FWD0, BODY_HASH, BODY_NOP, EVT_IDEM, EVT_LATCH, EVT_ONCE, EVT_STICKY,
+from ocr_amd.opstream import (BODY_FWD0, BODY_HASH, BODY_NOP, EVT_COUNTED, EVT_IDEM, EVT_LATCH, EVT_ONCE, EVT_STICKY,
                               LATCH_DECR, LATCH_INCR, MODE_NULL, MODE_RO, MODE_RW, Builder, cholesky_dag, layered_dag,
                               powerlaw_dag, stencil_dag)
 
@@ -100,6 +100,51 @@ def sticky_early_and_late():
     blocked = b.edt(1)                    # never fires
     b.add_dep(st_never, blocked, 0)
     return b.finish([late, early, en] + c, start)
+
+
+def counted_events():
+    """COUNTED events (hc-event.c:537-565,1176-1248): sticky until nbDeps waiters have been served, then destroyed;
+    waiters before and after the satisfy both count."""
+    b = Builder("counted_events")
+    start = b.evt(EVT_ONCE)
+    c = chain(b, 2, start)
+    # all registrations before the satisfy: fires both, destroyed
+    c1 = b.evt(EVT_COUNTED, 2)
+    w1, w2 = b.edt(1), b.edt(2)
+    b.add_dep(c1, w1, 0, MODE_RO)
+    b.add_dep(c1, w2, 0, MODE_RO)
+    b.add_dep(start, w2, 1, MODE_NULL)
+    b.script_satisfy(c[1], c1, b.outdb(c[1]))
+    # one early waiter, satisfied by main, two late waiters: the third registration destroys it
+    c2 = b.evt(EVT_COUNTED, 3)
+    d = b.db(0x2222)
+    e1 = b.edt(2)
+    b.add_dep(c2, e1, 0, MODE_RO)
+    b.add_dep(start, e1, 1, MODE_NULL)
+    b.satisfy(c2, d)
+    l1, l2 = b.edt(2), b.edt(2)
+    b.add_dep(c2, l1, 0, MODE_RO)
+    b.add_dep(start, l1, 1, MODE_NULL)
+    b.add_dep(c2, l2, 0, MODE_NULL)
+    b.add_dep(start, l2, 1, MODE_NULL)
+    # satisfied with NULL_GUID, only one of two registrations ever comes: stays satisfied
+    c3 = b.evt(EVT_COUNTED, 2)
+    b.satisfy(c3, 0)
+    h = b.edt(2)
+    b.add_dep(c3, h, 0, MODE_RO)
+    b.add_dep(start, h, 1, MODE_NULL)
+    # never satisfied: its waiter never fires
+    c4 = b.evt(EVT_COUNTED, 1)
+    blocked = b.edt(1)
+    b.add_dep(c4, blocked, 0)
+    # a COUNTED event feeding another event
+    c5 = b.evt(EVT_COUNTED, 1)
+    st = b.evt(EVT_STICKY)
+    b.add_dep(c5, st, 0)
+    g = b.edt(1)
+    b.add_dep(st, g, 0, MODE_RO)
+    b.script_satisfy(c[0], c5, b.outdb(c[0]))
+    return b.finish([w1, w2, e1, l1, l2, h, g] + c, start)
 
 
 def idem_double_satisfy():
@@ -229,7 +274,7 @@ def wide_fanin():
 
 
 SEMANTIC = [latch_decr_then_incr, latch_incr2_decr2, latch_init_counter, once_no_waiters, sticky_early_and_late,
-            idem_double_satisfy, mode_null_forces_null, db_and_null_sources, event_chain, forward_and_nop,
+            counted_events, idem_double_satisfy, mode_null_forces_null, db_and_null_sources, event_chain, forward_and_nop,
             destroy_and_unfired, wide_fanin]
 
 

@@ -15,8 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_programs.json")))["programs"]
 BIN = os.path.join(ROOT, "oracle", "_ref", "shimtests")
-# not on the engine yet: COUNTED events need the auto-destroy-after-nbDeps rule
-UNSUPPORTED = {n for n in FIX if "Counted" in n} | {"edtReturnEvent1"}
+UNSUPPORTED = set()
 RUNNABLE = sorted(n for n, e in FIX.items() if e.get("shim_builds") and n not in UNSUPPORTED)
 
 
