@@ -47,12 +47,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # eager: the RCCL communicator is built here
         else:
             dist.init_process_group(backend)
 
     from ocr_amd import engine, opstream
     if world > 1:
+        if backend == "nccl":
+            backend = collectives_selftest(torch, dist, local)
+        elif os.environ.get("OCRGPU_BENCH_HOST_GROUP"):      # rehearsal of the fallback plumbing
+            from ocr_amd import distributed as D
+            D.HOST_GROUP = dist.new_group(backend="gloo")
         return main_partitioned(args, torch, dist, rank, world, local, backend)
 
     # ---- build: every rank owns one partition = one independent layered DAG (seeded per rank) ----
@@ -144,6 +149,38 @@ def main():
         print(json.dumps(out))
 
 
+def collectives_selftest(torch, dist, local):
+    """The three collectives the exchange uses (count all-to-all, ragged uint8 all-to-all-v with empty splits, int64
+    all-gather) on RCCL, checked for content.  If RCCL refuses one of them the job falls back to a gloo group with
+    host-staged records (ocr_amd.distributed.HOST_GROUP) -- slower, still the same protocol -- and says so in
+    config.workload."""
+    import sys
+    W, r = dist.get_world_size(), dist.get_rank()
+    dev = torch.device("cuda", local)
+    try:
+        out_counts = [(r + d) % 3 for d in range(W)]
+        cnt_out = torch.tensor(out_counts, dtype=torch.int64, device=dev)
+        cnt_in = torch.empty_like(cnt_out)
+        dist.all_to_all_single(cnt_in, cnt_out)
+        cin = [int(x) for x in cnt_in.cpu().tolist()]
+        assert cin == [(s + r) % 3 for s in range(W)], cin
+        send = torch.full((sum(out_counts), 32), r, dtype=torch.uint8, device=dev)
+        recv = torch.empty((sum(cin), 32), dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(recv, send, output_split_sizes=cin, input_split_sizes=out_counts)
+        want = torch.cat([torch.full((cin[s], 32), s, dtype=torch.uint8) for s in range(W)]) if sum(cin) else recv.cpu()
+        assert torch.equal(recv.cpu(), want)
+        rows = [torch.empty_like(cnt_out) for _ in range(W)]
+        dist.all_gather(rows, cnt_out)
+        assert [int(x[0]) for x in rows] == [s % 3 for s in range(W)]
+        torch.cuda.synchronize()
+        return "nccl"
+    except Exception as ex:  # noqa: BLE001 -- any RCCL refusal lands here on every rank
+        print(f"[bench] rank {r}: RCCL collectives self-test failed ({type(ex).__name__}: {ex}); falling back to gloo", file=sys.stderr)
+        from ocr_amd import distributed as D
+        D.HOST_GROUP = dist.new_group(backend="gloo")   # every rank takes this branch: the failure is not rank-specific
+        return "gloo"
+
+
 def main_partitioned(args, torch, dist, rank, world, local, backend):
     """N > 1: ONE global DAG of world x n_edt EDTs (same layer count, layers world x wider), GUID space partitioned
     round-robin over the ranks; satisfies whose destination lives on another GPU are exchanged per level with an
@@ -153,9 +190,12 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     from ocr_amd.workloads import LayeredPartition
     cdev = "cpu" if backend == "gloo" else torch.device("cuda", local)
 
+    from ocr_amd import distributed as D
+    grp = D.HOST_GROUP                           # None unless the RCCL self-test failed
+
     def allreduce_sum(x):
         t = torch.tensor([int(x)], dtype=torch.int64, device=cdev)
-        dist.all_reduce(t)
+        dist.all_reduce(t, group=grp)
         return int(t.item())
 
     N, width = args.n_edt * world, args.width * world
@@ -174,7 +214,7 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
 
     def fence():
         torch.cuda.synchronize()
-        dist.barrier()
+        dist.barrier(group=grp)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -187,7 +227,7 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
     dt = float(t.item())
     st = part.eng.stats()
     assert sum(st.err) == 0, list(st.err)
@@ -219,7 +259,7 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
                          "alg_bytes_per_resolve": alg_bytes, "kernel_s_per_resolve": step_kernel_s},
         }
         print(json.dumps(out))
-    dist.barrier()
+    dist.barrier(group=grp)
     dist.destroy_process_group()
 
 

@@ -305,15 +305,22 @@ def resolve_lockstep(parts):
     return levels
 
 
+HOST_GROUP = None   # set to a gloo group to route every collective of the exchange through host memory
+
+
+def _host(dist):
+    return HOST_GROUP is not None or dist.get_backend() == "gloo"
+
+
 def exchange_records(dist, send, counts, device):
     """all-to-all-v of 32-byte records when the receive counts are NOT known yet: ``send[dst, :counts[dst]]`` goes
     to rank dst.  Returns (recv tensor, n)."""
     import torch
     W = dist.get_world_size()
-    cdev = "cpu" if dist.get_backend() == "gloo" else device
+    cdev = "cpu" if _host(dist) else device
     cnt_out = torch.as_tensor(np.asarray(counts, dtype=np.int64)).to(cdev)
     cnt_in = torch.empty_like(cnt_out)
-    dist.all_to_all_single(cnt_in, cnt_out)
+    dist.all_to_all_single(cnt_in, cnt_out, group=HOST_GROUP)
     cin = cnt_in.cpu().numpy()
     return exchange_payload(dist, send, counts, cin, device), int(cin.sum())
 
@@ -323,23 +330,23 @@ def exchange_payload(dist, send, counts_out, counts_in, device):
     "gloo" (CPU tests, or several ranks sharing one GPU) the records are staged through host memory."""
     import torch
     W = dist.get_world_size()
-    cdev = "cpu" if dist.get_backend() == "gloo" else device
+    cdev = "cpu" if _host(dist) else device
     pieces = [send[d, :int(counts_out[d])] for d in range(W) if int(counts_out[d])]
     sendbuf = (torch.cat(pieces) if pieces else send[0, :0]).contiguous().to(cdev)
     recv = torch.empty((int(np.sum(counts_in)), REC_BYTES), dtype=torch.uint8, device=cdev)
     dist.all_to_all_single(recv, sendbuf, output_split_sizes=[int(x) for x in counts_in],
-                           input_split_sizes=[int(x) for x in counts_out])
+                           input_split_sizes=[int(x) for x in counts_out], group=HOST_GROUP)
     return recv.to(device)
 
 
 def _dist_round(part, dist, fire):
     import torch
     W, rank = dist.get_world_size(), dist.get_rank()
-    cdev = "cpu" if dist.get_backend() == "gloo" else part.send.device
+    cdev = "cpu" if _host(dist) else part.send.device
     ready, _, counts = part.eng.step(1 if fire else 0, force_level=bool(fire), want_counts=True)
     vec = torch.tensor([int(c) for c in counts] + [int(ready)], dtype=torch.int64, device=cdev)
     rows = [torch.empty_like(vec) for _ in range(W)]
-    dist.all_gather(rows, vec)
+    dist.all_gather(rows, vec, group=HOST_GROUP)
     return torch.stack(rows).cpu().numpy()
 
 
