@@ -11,6 +11,7 @@ once, before the timed region, and is resident in HBM.  Prints ONE JSON line (se
                     [--no-cpu-baseline] [--no-parity]
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -47,9 +48,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # eager: the RCCL communicator is built here
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local),   # eager: the RCCL communicator is built here
+                                    timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
 
     from ocr_amd import engine, opstream
     if world > 1:

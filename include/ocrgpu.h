@@ -152,8 +152,15 @@ int ocrgpu_resolve(ocrgpu_engine_t *e, uint64_t max_levels, ocrgpu_stats_t *stat
  * when nothing is ready here still count one (empty) level, so partitions stepping in lockstep keep the same
  * level numbering.  *has_ready_out = 1 when EDTs are waiting to fire; *pending_records_out = queued satisfies. */
 #define OCRGPU_STEP_FORCE_LEVEL 1u
+/* before anything else: if the last level recorded is a forced one in which nothing fired, forget it (a lockstep
+ * driver that learns only afterwards that every partition was idle uses this to undo its final probe level) */
+#define OCRGPU_STEP_DROP_EMPTY_LEVEL 2u
 int ocrgpu_step(ocrgpu_engine_t *e, uint32_t fire_levels, uint32_t flags, uint64_t *has_ready_out,
                 uint64_t *pending_records_out, uint32_t *send_counts_out /* host [n_locations] or NULL */);
+
+/* facts about the last ocrgpu_step / ocrgpu_resolve, no device access: out4[0] = ready-log entries of the level it
+ * fired (0 = it fired nothing), [1] = current level, [2] = levels recorded, [3] = satisfies still queued */
+int ocrgpu_step_info(ocrgpu_engine_t *e, uint64_t *out4);
 
 /* EDTs whose body is host code (OCRBODY_HOST): GET_WORK + the depv hand-over of taskExecute
  * (hcSchedulerHeuristicGetEdt hc-scheduler-heuristic.c:148-199, workpile pop ocr-workpile.h:39-84, hc-task.c:1864-1916).
@@ -180,6 +187,10 @@ int ocrgpu_exchange_config(ocrgpu_engine_t *e, uint32_t n_locations, void *send_
 int ocrgpu_exchange_counts(ocrgpu_engine_t *e, uint32_t *counts_out /* host, [n_locations] */);
 int ocrgpu_exchange_reset(ocrgpu_engine_t *e);
 int ocrgpu_exchange_apply(ocrgpu_engine_t *e, const void *records, uint64_t n, int where);
+/* the receive side of an EQUAL-SPLIT all-to-all: records_dev (device) holds n_src regions of stride_records records,
+ * region s carrying counts[s] (host array) valid records from partition s */
+int ocrgpu_exchange_apply_strided(ocrgpu_engine_t *e, const void *records_dev, uint32_t n_src, uint64_t stride_records,
+                                  const uint32_t *counts);
 
 /* snapshot / restore of all mutable dependence state (benchmark loops re-arm a built DAG) */
 int ocrgpu_snapshot(ocrgpu_engine_t *e);

@@ -589,6 +589,11 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 // Start a run at launch index K0: seed state[(K0-1)&1] from the between-runs view (single thread).
 __global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) {
     Ctrl *c = d.ctrl;
+    if (force_level & 2u) { // OCRGPU_STEP_DROP_EMPTY_LEVEL: forget a trailing forced level in which nothing fired
+        const u32 lv = c->level;
+        if (lv != 0xFFFFFFFFu && lv < d.max_levels && d.level_start[lv] == d.level_start[lv + 1]) { c->level = lv - 1; c->n_levels = lv; }
+        force_level &= 1u;
+    }
     State P; memset(&P, 0, sizeof P);
     P.mode = MODE_EVENTS; P.level = c->level; P.r_begin = P.r_end = c->r_end; P.q_begin = P.q_end = c->q_begin;
     P.done = 0; P.allow_fire = allow_fire; P.r_total = c->r_tail; P.q_total = c->q_tail > d.q_cap ? d.q_cap : c->q_tail;
@@ -836,10 +841,7 @@ __global__ void k_script_ops(Dev d, u64 n, const ocrgpu_script_op_t *ops, u32 sc
 
 // Apply satisfies received from other partitions: resolve the guid in OUR table, clone the DB into a proxy
 // entry, and queue an ordinary record (the next EVENTS phase does the rest).
-__global__ void k_exchange_apply(Dev d, u64 n, const SendRec *recs, u32 proxy_base) {
-    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    SendRec r = recs[i];
+__device__ void apply_record(const Dev &d, const SendRec &r, u32 proxy) {
     if (r.flags & XF_DESTROY) {
         u64 v = (OCRGPU_GUID_LOCATION(r.guid) == d.location && is_event_kind(OCRGPU_GUID_KIND(r.guid))) ? gtab_get(d, r.guid) : 0;
         if (!v) { bad_op(d); return; }
@@ -850,9 +852,21 @@ __global__ void k_exchange_apply(Dev d, u64 n, const SendRec *recs, u32 proxy_ba
     u32 didx, dslot, dflag;
     if (OCRGPU_GUID_LOCATION(r.guid) != d.location || !resolve_dst(d, r.guid, r.slot, didx, dflag, dslot)) { bad_op(d); return; }
     u32 pay = 0;
-    if (r.flags & XF_HAS_DB) { d.db[proxy_base + i] = make_ulonglong2(r.value, r.tag); pay = proxy_base + (u32)i + 1; }
+    if (r.flags & XF_HAS_DB) { d.db[proxy] = make_ulonglong2(r.value, r.tag); pay = proxy + 1; }
     if ((dflag & RF_DST_EDT) && (r.flags & XF_MODE_NULL)) dflag |= RF_MODE_NULL;
     q_push(d, Rec{didx, pay, dslot, dflag});
+}
+__global__ void k_exchange_apply(Dev d, u64 n, const SendRec *recs, u32 proxy_base) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i < n) apply_record(d, recs[i], proxy_base + (u32)i);
+}
+// one receive buffer of n_src regions of `stride` records (an equal-split all-to-all): region s holds cnt[s] records,
+// cnt[n_src + s] = records in the regions before it
+__global__ void k_exchange_apply_strided(Dev d, u32 n_src, u64 stride, u32 max_cnt, const u32 *cnt, const SendRec *recs, u32 proxy_base) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    u32 s = (u32)(i / max_cnt), k = (u32)(i % max_cnt);
+    if (s >= n_src || k >= cnt[s]) return;
+    apply_record(d, recs[(u64)s * stride + k], proxy_base + cnt[n_src + s] + k);
 }
 __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
 __global__ void k_exchange_counts(Dev d, u32 *out) { if (threadIdx.x < d.n_loc) { u32 c = d.send_cnt[threadIdx.x * 32]; out[threadIdx.x] = c > d.send_cap ? d.send_cap : c; } }
@@ -1467,7 +1481,7 @@ extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *
     ENTER(e);
     // one run: close pending satisfies, fire at most `fire_levels` levels (an empty one if forced), close again;
     // 3 launches cover the common single-level case (FIRE, the no-op that notices quiescence, one spare)
-    int r = run_steps(e, fire_levels, ~0ull, true, (flags & OCRGPU_STEP_FORCE_LEVEL) ? 1u : 0u, fire_levels == 1 ? 3u : 2u);
+    int r = run_steps(e, fire_levels, ~0ull, true, flags & (OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_DROP_EMPTY_LEVEL), fire_levels == 1 ? 3u : 2u);
     if (r) return r;
     const State *S = (const State *)e->pinned_done; // the poll that saw `done` brought the final state and counters
     if (has_ready_out) *has_ready_out = S->r_total > S->r_end ? 1 : 0;
@@ -1518,6 +1532,13 @@ extern "C" int ocrgpu_pop_ready(ocrgpu_engine_t *e, u64 max_edts, u64 max_deps, 
     return 0;
 }
 
+extern "C" int ocrgpu_step_info(ocrgpu_engine_t *e, u64 *out4) {
+    if (!e || !out4) FAIL(OCRGPU_EINVAL, "null argument");
+    const State *S = (const State *)e->pinned_done; // what the last run's final poll brought back
+    out4[0] = S->r_end - S->r_begin; out4[1] = S->level; out4[2] = S->n_levels; out4[3] = S->q_total > S->q_end ? S->q_total - S->q_end : 0;
+    return 0;
+}
+
 // ---- cross-partition exchange (replaces the comm-platform's sendMessage/pollMessage for DEP_SATISFY,
 //      ocr/src/inc/ocr-comm-platform.h:55-199; the transport itself -- RCCL all-to-all -- is the caller's) ----
 extern "C" int ocrgpu_exchange_config(ocrgpu_engine_t *e, u32 n_locations, void *send_dev_buf, u64 records_per_dest, u64 max_remote_dsts) {
@@ -1547,6 +1568,26 @@ extern "C" int ocrgpu_exchange_reset(ocrgpu_engine_t *e) {
     if (!e->d.send_cnt) FAIL(OCRGPU_EINVAL, "exchange not configured");
     k_exchange_reset<<<1, 1024, 0, e->stream>>>(e->d);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int ocrgpu_exchange_apply_strided(ocrgpu_engine_t *e, const void *recs_dev, u32 n_src, u64 stride_records, const u32 *counts) {
+    ENTER(e);
+    if (n_src == 0) return 0;
+    if (!recs_dev || !counts || n_src > 1024) FAIL(OCRGPU_EINVAL, "bad argument");
+    std::vector<u32> cp(2 * (size_t)n_src);
+    u64 total = 0; u32 mx = 0;
+    for (u32 s = 0; s < n_src; ++s) {
+        if (counts[s] > stride_records) FAIL(OCRGPU_EINVAL, "count %u of source %u exceeds the region (%llu records)", counts[s], s, (unsigned long long)stride_records);
+        cp[s] = counts[s]; cp[n_src + s] = (u32)total; total += counts[s]; if (counts[s] > mx) mx = counts[s];
+    }
+    if (total == 0) return 0;
+    if ((u64)e->n_db + total > e->cfg.max_db) FAIL(OCRGPU_ENOMEM, "max_db=%u exhausted by proxy datablocks", e->cfg.max_db);
+    int r = stage_reserve(e, rup(8 * (size_t)n_src)); if (r) return r;
+    const u32 *dc; if ((r = stage_in(e, cp.data(), 2 * (u64)n_src, OCRGPU_HOST, &dc))) return r;
+    k_exchange_apply_strided<<<nblk((u64)n_src * mx), 256, 0, e->stream>>>(e->d, n_src, stride_records, mx, dc, (const SendRec *)recs_dev, e->n_db);
+    e->n_db += (u32)total;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream)); // `cp` was staged from the stack
     return 0;
 }
 extern "C" int ocrgpu_exchange_apply(ocrgpu_engine_t *e, const void *recs, u64 n, int where) {

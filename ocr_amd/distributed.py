@@ -366,12 +366,52 @@ def distributed_exchange(part, dist, M=None):
 
 def resolve_distributed(part, dist):
     """One process per GPU (torch.distributed, backend "nccl" == RCCL).  Returns the number of levels fired."""
+    if getattr(part, "may_cascade", True) is False:
+        return _resolve_one_collective_per_level(part, dist)
     W = dist.get_world_size()
     levels = 0
     M = distributed_exchange(part, dist)
     while M[:, W].sum() > 0:
         M = distributed_exchange(part, dist, _dist_round(part, dist, True))
         levels += 1
+    return levels
+
+
+def _resolve_one_collective_per_level(part, dist):
+    """For DAGs that declare ``may_cascade = False``: no satisfy that arrives from another partition can itself send
+    a satisfy to a third one (no event -> remote waiter chains), so every record in flight was produced by the level
+    just fired and ONE exchange per level settles it.  Per level: one engine step (closes the records applied last
+    round, fires the level, one synchronisation) and one EQUAL-SPLIT all-to-all whose regions carry a 32-byte header
+    {records for you, my activity} in their last record slot.  Every rank opens every level (forced when it has
+    nothing ready); the loop ends after the first level in which no rank fired or sent anything, and that probe level
+    is dropped again."""
+    import torch
+    W, rank = dist.get_world_size(), dist.get_rank()
+    host = _host(dist)
+    dev = part.send.device
+    C = part.send.shape[1] - 1                      # record slots per region; slot C holds the header
+    distributed_exchange(part, dist)                # main-time satisfies (the start event's fan-out) settle the general way
+    hdr = torch.zeros((W, 4), dtype=torch.int64)
+    recv = torch.empty(part.send.shape, dtype=torch.uint8, device="cpu" if host else dev)
+    levels = 0
+    while True:
+        _, _, counts = part.eng.step(1, force_level=True, want_counts=True)
+        if int(counts.max()) > C:
+            raise RuntimeError(f"send region overflow: {int(counts.max())} records for one partition, room for {C}")
+        hdr[:, 0] = torch.from_numpy(counts.astype(np.int64))
+        hdr[:, 1] = part.eng.step_info()[0] + int(counts.sum())
+        part.send[:, C, :] = hdr.view(torch.uint8).to(dev)
+        dist.all_to_all_single(recv.view(-1), (part.send.cpu() if host else part.send).view(-1), group=HOST_GROUP)
+        h = recv[:, C, :].cpu().contiguous().view(torch.int64).numpy()
+        part.eng.exchange_reset()
+        cin = h[:, 0].astype(np.uint32)
+        if cin.any():
+            rdev = recv.to(dev) if host else recv
+            part.eng.exchange_apply_strided(rdev.data_ptr(), W, C + 1, cin)
+        if h[:, 1].sum() == 0:
+            break
+        levels += 1
+    part.eng.step(0, drop_empty_level=True)
     return levels
 
 

@@ -55,7 +55,7 @@ EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error
            "ocrgpu_guid_reserve", "ocrgpu_guid_put", "ocrgpu_guid_get", "ocrgpu_guid_remove",
            "ocrgpu_event_create", "ocrgpu_db_create", "ocrgpu_edt_create", "ocrgpu_edt_set_scripts",
            "ocrgpu_set_hash_tag_base", "ocrgpu_add_dependence", "ocrgpu_event_satisfy_slot", "ocrgpu_event_destroy",
-           "ocrgpu_resolve", "ocrgpu_step", "ocrgpu_pop_ready", "ocrgpu_exchange_config", "ocrgpu_exchange_counts",
+           "ocrgpu_resolve", "ocrgpu_step", "ocrgpu_step_info", "ocrgpu_pop_ready", "ocrgpu_exchange_apply_strided", "ocrgpu_exchange_config", "ocrgpu_exchange_counts",
            "ocrgpu_exchange_reset", "ocrgpu_exchange_apply", "ocrgpu_snapshot", "ocrgpu_restore", "ocrgpu_sync", "ocrgpu_read_edts",
            "ocrgpu_read_events", "ocrgpu_read_dbs", "ocrgpu_read_fired", "ocrgpu_get_stats"]
 
@@ -221,16 +221,23 @@ class Engine:
         self._chk(self.lib.ocrgpu_resolve(self.h, C.c_uint64(max_levels), C.byref(st)))
         return st
 
-    def step(self, fire_levels=1, force_level=False, want_counts=False):
+    def step(self, fire_levels=1, force_level=False, want_counts=False, drop_empty_level=False):
         """Close pending satisfies, fire at most ``fire_levels`` levels, close again.  Returns
         (has_ready, pending_records[, send_counts]) -- all from the one synchronisation the run ends with."""
         hr, pr = C.c_uint64(), C.c_uint64()
         counts = np.zeros(self.n_locations, np.uint32) if want_counts else None
-        self._chk(self.lib.ocrgpu_step(self.h, C.c_uint32(fire_levels), C.c_uint32(1 if force_level else 0),
+        self._chk(self.lib.ocrgpu_step(self.h, C.c_uint32(fire_levels),
+                                       C.c_uint32((1 if force_level else 0) | (2 if drop_empty_level else 0)),
                                        C.byref(hr), C.byref(pr), _ptr(counts)))
         if want_counts:
             return bool(hr.value), int(pr.value), counts
         return bool(hr.value), int(pr.value)
+
+    def step_info(self):
+        """(ready-log entries of the level the last step fired, level, levels recorded, queued satisfies)."""
+        out = (C.c_uint64 * 4)()
+        self._chk(self.lib.ocrgpu_step_info(self.h, out))
+        return tuple(int(x) for x in out)
 
     # ---- cross-partition exchange ----
     def exchange_config(self, n_locations, send_dev_ptr, records_per_dest, max_remote_dsts):
@@ -248,6 +255,11 @@ class Engine:
 
     def exchange_apply(self, dev_ptr, n):
         self._chk(self.lib.ocrgpu_exchange_apply(self.h, C.c_void_p(dev_ptr), C.c_uint64(n), DEVICE))
+
+    def exchange_apply_strided(self, dev_ptr, n_src, stride_records, counts):
+        counts = np.ascontiguousarray(counts, np.uint32)
+        self._chk(self.lib.ocrgpu_exchange_apply_strided(self.h, C.c_void_p(dev_ptr), C.c_uint32(n_src),
+                                                         C.c_uint64(stride_records), _ptr(counts)))
 
     def snapshot(self):
         self._chk(self.lib.ocrgpu_snapshot(self.h))

@@ -59,10 +59,15 @@ class LayeredPartition:
         # ---- engine ----
         n_my = len(self.mine) + (1 if rank == 0 else 0)
         n_reg = len(self.src) + n_leaves_local + (width + 1 if rank == 0 else 0)
-        cap = max(4096, int(1.3 * (len(self.src) * (W - 1) // max(W, 1)) // max(N // width, 1)) + 4 * width // W + 4096) if W > 1 else 16
-        if W > 1 and rank == 0:
-            cap = max(cap, width + 4096)
+        # records per (level, destination): the remote edges of one level spread evenly over W-1 partitions; 2x the
+        # mean + slack (they are Poisson-like: sd ~ sqrt(mean)); the start event's fan-out is width/W per destination.
+        # One more slot per region for the header of the one-collective-per-level exchange.
+        per_pair = self.n_edges_global // max(N // width - 1, 1) // (W * W)    # from global figures: every rank must get the same cap
+        cap = (max(2 * per_pair, width // W + 1024) + 4096 + 1) if W > 1 else 16
         self.send_cap = cap
+        # no event of this DAG that a remote satisfy can reach has a remote waiter (the latch and the sink EDT both
+        # live on rank 0; the start event is satisfied by rank 0 itself before the first level)
+        self.may_cascade = False
         self.send = torch.zeros((W, cap, REC_BYTES), dtype=torch.uint8, device=f"cuda:{device}")
         n_in = int(self.depc_mine.sum()) + 16        # upper bound on records this rank can receive per resolve
         self.eng = Engine(max_edt=n_my, max_evt=2, max_db=(n_in if W > 1 else 0) + 16,

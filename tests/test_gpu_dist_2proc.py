@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, n, width, q):
+def _worker(rank, world, port, n, width, general, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch
@@ -28,6 +28,8 @@ def _worker(rank, world, port, n, width, q):
         return int(t.item())
 
     part = LayeredPartition(n, width, rank, world, allreduce_sum=allreduce_sum).build()
+    if general:
+        part.may_cascade = True                      # the settle-until-quiet protocol instead of one collective per level
     distributed_exchange(part, dist)
     part.eng.snapshot()
     out = None
@@ -44,20 +46,22 @@ def _worker(rank, world, port, n, width, q):
     q.put(out)
 
 
-def test_two_processes_one_gpu_gloo():
+@pytest.mark.parametrize("world,general", [(2, False), (2, True), (3, False)])
+def test_processes_sharing_one_gpu_gloo(world, general):
     from ocr_amd.opstream import layered_dag
     from oracle import ref as O
-    n, width, world = 40_000, 1000, 2
+    width = 1200 if world == 3 else 1000
+    n = 36_000 if world == 3 else 40_000
     ref = O.run_restatement(layered_dag(n, width))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, width, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, width, general, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=240) for _ in range(world)]
+    results = [q.get(timeout=90) for _ in range(world)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
