@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "ocrgpu.h"
 #include "ocr_opstream.h"
 
@@ -395,7 +396,8 @@ __device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, 
 }
 
 #ifdef OCRGPU_STAMPS
-#define STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { u64 _t = __builtin_amdgcn_s_memrealtime(); d.dbg[k] += _t - _t0; _t0 = _t; } } while (0)
+#define STAMP(k) do { if (threadIdx.x == 0) { u64 _t = __builtin_amdgcn_s_memrealtime(); if (blockIdx.x == 0) { d.dbg[k] += _t - _t0; _t0 = _t; } \
+                                              if (K == (u32)d.dbg[15]) d.dbg[16 + 8 * blockIdx.x + 2 + (k)] = _t; } } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #endif
@@ -405,7 +407,7 @@ template <bool NANNY>
 __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #ifdef OCRGPU_STAMPS
     u64 _t0 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && K == (u32)d.dbg[15]) d.dbg[16 + 2 * blockIdx.x] = _t0; // per-workgroup entry time of ONE chosen launch
+    if (threadIdx.x == 0 && K == (u32)d.dbg[15]) d.dbg[16 + 8 * blockIdx.x] = _t0; // per-workgroup entry time of ONE chosen launch
 #endif
     __shared__ Seg seg[BLK];
     __shared__ u32 wave_sums[4];
@@ -578,11 +580,16 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     __syncthreads();
     if (threadIdx.x == 0) {
         u64 a0 = red[0] + red[3] + red[6] + red[9], a1 = red[1] + red[4] + red[7] + red[10], a2 = red[2] + red[5] + red[8] + red[11];
-        if (a0 | a1 | a2) { u64 *bs = d.blk_stats + 4 * blockIdx.x; bs[0] += a0; bs[1] += a1; bs[2] += a2; }
+        if (a0 | a1 | a2) { // no-return atomics on this workgroup's own slots: fire-and-forget (a plain += is a load the exit waits for)
+            unsigned long long *bs = (unsigned long long *)(d.blk_stats + 4 * blockIdx.x);
+            if (a0) atomicAdd(bs, (unsigned long long)a0);
+            if (a1) atomicAdd(bs + 1, (unsigned long long)a1);
+            if (a2) atomicAdd(bs + 2, (unsigned long long)a2);
+        }
     }
     STAMP(5);
 #ifdef OCRGPU_STAMPS
-    if (threadIdx.x == 0 && K == (u32)d.dbg[15]) d.dbg[17 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && K == (u32)d.dbg[15]) d.dbg[17 + 8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -1160,7 +1167,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.level_start, 4 * ((size_t)d.max_levels + 2)));
     TRY(dalloc(e, (void **)&d.q, sizeof(Rec) * (size_t)q_cap, false));
     TRY(dalloc(e, (void **)&d.blk_stats, 8 * 4 * MAX_GRID));
-    TRY(dalloc(e, (void **)&d.dbg, 8 * (16 + 2 * MAX_GRID)));
+    TRY(dalloc(e, (void **)&d.dbg, 8 * (16 + 8 * MAX_GRID)));
     { u64 k = getenv("OCRGPU_STAMP_K") ? (u64)atoll(getenv("OCRGPU_STAMP_K")) : 0; (void)hipMemcpyAsync(&d.dbg[15], &k, 8, hipMemcpyHostToDevice, e->stream); (void)hipStreamSynchronize(e->stream); }
     TRY(dalloc(e, (void **)&d.scripts, sizeof(Script) * ((size_t)cfg->max_edt + 1024)));
     TRY(dalloc(e, (void **)&d.gtab, 16 * (size_t)cap));
@@ -1187,12 +1194,20 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     { u64 h[16]; if (e->d.dbg && hipMemcpy(h, e->d.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
         fprintf(stderr, "[stamps, 10ns ticks of workgroup 0 summed over %llu launches] entry %llu | A(loads) %llu | scan %llu | fanout %llu | body %llu | ticket %llu\n",
                 (unsigned long long)e->launches_total, (unsigned long long)h[0], (unsigned long long)h[1], (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)h[4], (unsigned long long)h[5]);
-        std::vector<u64> hb(16 + 2 * MAX_GRID);
+        std::vector<u64> hb(16 + 8 * MAX_GRID);
         if (hipMemcpy(hb.data(), e->d.dbg, 8 * hb.size(), hipMemcpyDeviceToHost) == hipSuccess) {
-            u64 t0 = ~0ull, e_first = ~0ull, e_last = 0, s_last = 0; int n = 0, last_blk = -1;
-            for (int b = 0; b < MAX_GRID; ++b) { u64 st = hb[16 + 2 * b], en = hb[17 + 2 * b]; if (!st) continue; if (st < t0) t0 = st; if (st > s_last) s_last = st; if (en) { ++n; if (en < e_first) e_first = en; if (en > e_last) { e_last = en; last_blk = b; } } }
-            if (n) fprintf(stderr, "[stamps] launch K=%llu: %d working wgs; last entry +%llu, first end +%llu, last end +%llu (wg %d), wg0 end +%llu  (10ns ticks after the first entry)\n",
-                           (unsigned long long)hb[15], n, (unsigned long long)(s_last - t0), (unsigned long long)(e_first - t0), (unsigned long long)(e_last - t0), last_blk, (unsigned long long)(hb[17] - t0));
+            u64 t0 = ~0ull; int n = 0;
+            for (int b = 0; b < MAX_GRID; ++b) { u64 st = hb[16 + 8 * b]; if (st && hb[17 + 8 * b] && st < t0) t0 = st; }
+            // per phase: min / median / max over the working workgroups, 10ns ticks after the first entry
+            static const char *nm[8] = {"entry", "exit", "decided", "lines", "scan", "fanout", "loopend", "stats"};
+            for (int ph = 0; ph < 8; ++ph) {
+                std::vector<u64> v;
+                for (int b = 0; b < MAX_GRID; ++b) { if (!hb[17 + 8 * b]) continue; u64 t = hb[16 + 8 * b + ph]; if (t >= t0) v.push_back(t - t0); }
+                if (v.empty()) continue;
+                std::sort(v.begin(), v.end()); n = (int)v.size();
+                fprintf(stderr, "[stamps K=%llu] %-8s n=%d min %llu med %llu p90 %llu max %llu\n", (unsigned long long)hb[15], nm[ph], n,
+                        (unsigned long long)v[0], (unsigned long long)v[n / 2], (unsigned long long)v[n * 9 / 10], (unsigned long long)v[n - 1]);
+            }
         }
 } }
 #endif
