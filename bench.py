@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--width", type=int, default=10_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--cpu-sample-edts", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-edts", type=int, default=4_000_000)
     args = ap.parse_args()
 
     import torch
@@ -265,7 +265,7 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     dist.destroy_process_group()
 
 
-def profiled_traffic(args, tag="r01b_config2"):
+def profiled_traffic(args, tag="r01c_config2"):
     """HBM bytes per k_step launch from the committed PMC passes (profiles/<tag>_pmc_summary.txt: FETCH_SIZE and
     WRITE_SIZE in KB, separate rocprofv3 --pmc runs of this same workload).  Counters cannot be read inside this
     process, so the figure is the profiled one; None for any other workload shape."""
@@ -296,10 +296,20 @@ def cpu_baseline(args):
     n -= n % width
     twin = opstream.layered_dag(n, width)
     if O.reference_available("perf"):
-        _, info = O.run_reference(twin, workers=1, guid="PTR", flavour="perf", want_result=False, timeout=900)
-        return {"value": info["sat_per_s"], "unit": "satisfactions/s", "cores": 1, "kind": "reference",
+        # 1 worker and min(8, host share) workers: the reference's HC scheduler does not scale on this workload
+        # (one finish latch, work-stealing deques), so the better of the two is reported with its worker count
+        tried = {}
+        for w in (1, min(8, max(1, (os.cpu_count() or 1)))):
+            if w in tried:
+                continue
+            _, info = O.run_reference(twin, workers=w, guid="PTR", flavour="perf", want_result=False, timeout=900)
+            tried[w] = info
+        best = max(tried, key=lambda w: tried[w]["sat_per_s"])
+        info = tried[best]
+        return {"value": info["sat_per_s"], "unit": "satisfactions/s", "cores": best, "kind": "reference",
                 "sample": f"layered DAG twin, {n} EDTs in layers of {width} ({info['edges']} satisfactions in "
-                          f"{info['resolve_s']:.2f} s), 1 HC worker, timed first-satisfy..sink"}
+                          f"{info['resolve_s']:.2f} s), {best} HC worker(s), timed first-satisfy..sink",
+                "by_workers": {str(w): round(i["sat_per_s"], 1) for w, i in tried.items()}}
     t0 = time.perf_counter()
     _, st = O.run_restatement(twin, return_stats=True)
     dt = time.perf_counter() - t0
