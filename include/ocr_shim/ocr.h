@@ -145,6 +145,14 @@ void _ocrAssert(bool val, const char *str, const char *file, u32 line);
 #define OCR_EINVAL 22
 #define OCR_ENOMEM 12
 #define OCR_ENOTSUP 95
+#define OCR_EGUIDEXISTS 100
+
+/* labeled creation (ocr/inc/ocr-types.h:503-520): the guid passed in names the object to create */
+#define GUID_PROP_NONE ((u16)0x0)
+#define GUID_PROP_IS_LABELED ((u16)0x1000)
+#define GUID_PROP_CHECK ((u16)0x3000)   /* + report OCR_EGUIDEXISTS instead of creating twice */
+#define GUID_PROP_BLOCK ((u16)0x5000)
+ocrGuid_t addValueToGuid(ocrGuid_t input, u64 value);   /* ocr/inc/ocr-types.h:56 */
 
 /* the program's entry point, defined by the program */
 ocrGuid_t mainEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]);

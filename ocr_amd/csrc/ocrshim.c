@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "ocr.h"
+#include "extensions/ocr-labeling.h"
 #include "ocrgpu.h"
 #include "ocr_opstream.h"
 
@@ -100,6 +101,7 @@ static void *dbmap_take(u64 g) {
 enum { C_EVT_CREATE, C_DB_CREATE, C_EDT_CREATE, C_ADD_DEP, C_SATISFY, C_EVT_DESTROY, C_DB_DESTROY, N_CLASS };
 typedef struct { u8 cls, mode; u16 pad; u32 slot; u32 round; s32 arg; u64 a, b, c; u64 seq; } Op;
 static Op *ops; static size_t n_ops, cap_ops;
+static u64 flush_epoch;          /* bumped by every flush(): tells whether a labeled create is still in the queue */
 /* per-body program-order state */
 static u32 cur_round; static int cur_cls;
 typedef struct { u64 evt; u32 slot; } Touched;
@@ -163,6 +165,7 @@ static void batch_room(size_t n) {
 
 /* apply the queue: one C-ABI call per (round, class) */
 static void flush(void) {
+    ++flush_epoch;
     if (!n_ops) return;
     qsort(ops, n_ops, sizeof *ops, op_cmp);
     size_t i = 0;
@@ -209,6 +212,96 @@ static void flush(void) {
     n_ops = 0;
 }
 
+/* ---- labeled guids (ocr/src/guid/labeled/labeled-guid.c, ocr/src/api/extensions/ocr-labeling.c) ------------- */
+typedef struct { u64 first, n; u32 kind; ocrGuidMapFunc_t fn; s64 *params; } Range;
+static Range *ranges; static size_t n_range, cap_range;
+#define KIND_GUIDMAP 15u /* OCR_GUID_GUIDMAP (ocr-guid-kind.h:35); host-side handle */
+/* guids at which a labeled object has been created: open-addressing set */
+static u64 *labset; static u8 *labalive; static u32 *labround; static u64 *labepoch; static size_t labset_cap, labset_n;
+static size_t labset_find(u64 g) { /* slot of g, or of the free slot where it would go */
+    size_t h = db_hash(g) & (labset_cap - 1);
+    while (labset[h] && labset[h] != g) h = (h + 1) & (labset_cap - 1);
+    return h;
+}
+/* 1 = the label is free (never used, or its object was destroyed) and is now taken by the running body.  0 = it is
+ * in use; if its create is still queued (another EDT of this level made it), the running body's later ops are moved
+ * to that create's round so that they reach the engine after it. */
+static int labset_add(u64 g, int cls) {
+    if (2 * (labset_n + 1) > labset_cap) {
+        size_t oc = labset_cap; u64 *old = labset, *olde = labepoch; u8 *olda = labalive; u32 *oldr = labround;
+        labset_cap = oc ? 2 * oc : 1024;
+        labset = calloc(labset_cap, sizeof *labset); labalive = calloc(labset_cap, 1);
+        labround = calloc(labset_cap, sizeof *labround); labepoch = calloc(labset_cap, sizeof *labepoch);
+        if (!labset || !labalive || !labround || !labepoch) die("out of host memory");
+        for (size_t i = 0; i < oc; ++i) if (old[i]) { size_t h = labset_find(old[i]); labset[h] = old[i]; labalive[h] = olda[i]; labround[h] = oldr[i]; labepoch[h] = olde[i]; }
+        free(old); free(olda); free(oldr); free(olde);
+    }
+    size_t h = labset_find(g);
+    if (labset[h] == g && labalive[h]) {
+        if (labepoch[h] == flush_epoch && (labround[h] >> 3) >= cur_round) {
+            if ((labround[h] >> 3) > cur_round || (int)(labround[h] & 7u) > cur_cls) { cur_round = labround[h] >> 3; cur_cls = (int)(labround[h] & 7u); n_touched = 0; }
+        }
+        return 0;
+    }
+    if (labset[h] != g) { labset[h] = g; ++labset_n; }
+    labalive[h] = 1; labround[h] = ((cur_round + (cls < cur_cls ? 1u : 0u)) << 3) | (u32)cls; labepoch[h] = flush_epoch; /* where emit(cls) will put it */
+    return 1;
+}
+static void labset_release(u64 g) { if (labset_cap) { size_t h = labset_find(g); if (labset[h] == g) labalive[h] = 0; } }
+/* what a create call does with GUID_PROP_IS_LABELED: *guid is an input; 0 = go on and create at `out` */
+static u8 labeled_guid(const ocrGuid_t *guid, u16 props, u32 want_kind, int cls, u64 *out) {
+    if (!(props & GUID_PROP_IS_LABELED)) { *out = 0; return 0; }
+    u64 g = (u64)guid->guid;
+    if (OCRGPU_GUID_KIND(g) != want_kind) return OCR_EINVAL;
+    if (!labset_add(g, cls)) return OCR_EGUIDEXISTS; /* GUID_PROP_CHECK / _BLOCK; without them the reference would create twice: a user error */
+    *out = g;
+    return 0;
+}
+static u8 range_new(ocrGuid_t *out, u64 n, ocrGuidUserKind kind, ocrGuidMapFunc_t fn, s64 *params, u32 numParams) {
+    if (!out || n == 0 || kind == GUID_USER_NONE || kind == GUID_USER_EDT_TEMPLATE || (u32)kind >= 32) return OCR_EINVAL;
+    u64 *tmp = xrealloc(NULL, 8 * (size_t)n);
+    CHK(ocrgpu_guid_reserve(G, (u32)kind, n, tmp, OCRGPU_HOST));   /* consecutive counters: first + i */
+    GROW(ranges, n_range, cap_range);
+    Range *r = &ranges[n_range];
+    r->first = tmp[0]; r->n = n; r->kind = (u32)kind; r->fn = fn; r->params = NULL;
+    if (numParams && params) { r->params = xrealloc(NULL, 8 * (size_t)numParams); memcpy(r->params, params, 8 * (size_t)numParams); }
+    free(tmp);
+    out->guid = (intptr_t)(((u64)KIND_GUIDMAP << 49) | (u64)(++n_range));
+    return 0;
+}
+static Range *range_of(ocrGuid_t g) {
+    u64 v = (u64)g.guid;
+    if (OCRGPU_GUID_KIND(v) != KIND_GUIDMAP || (v & 0xFFFFFFFFu) == 0 || (v & 0xFFFFFFFFu) > n_range) return NULL;
+    return &ranges[(v & 0xFFFFFFFFu) - 1];
+}
+u8 ocrGuidRangeCreate(ocrGuid_t *rangeGuid, u64 n, ocrGuidUserKind kind) { return range_new(rangeGuid, n, kind, NULL, NULL, 0); }
+u8 ocrGuidMapCreate(ocrGuid_t *mapGuid, u32 numParams, ocrGuidMapFunc_t fn, s64 *params, u64 n, ocrGuidUserKind kind) {
+    if (!fn) return OCR_EINVAL;
+    return range_new(mapGuid, n, kind, fn, params, numParams);
+}
+u8 ocrGuidMapDestroy(ocrGuid_t mapGuid) { return range_of(mapGuid) ? 0 : OCR_EINVAL; }
+ocrGuid_t addValueToGuid(ocrGuid_t input, u64 value) { ocrGuid_t r = { input.guid + (intptr_t)value }; return r; }
+u8 ocrGuidFromIndex(ocrGuid_t *out, ocrGuid_t rangeGuid, u64 idx) {
+    Range *r = range_of(rangeGuid);
+    if (!out || !r || idx >= r->n) return OCR_EINVAL;
+    out->guid = (intptr_t)(r->first + idx);
+    return 0;
+}
+u8 ocrGuidFromLabel(ocrGuid_t *out, ocrGuid_t mapGuid, s64 *tuple) {
+    Range *r = range_of(mapGuid);
+    if (!out || !r || !r->fn) return OCR_EINVAL;
+    ocrGuid_t start = { (intptr_t)r->first };
+    *out = r->fn(start, 1, r->params, tuple);          /* stride 1: counters are consecutive */
+    u64 g = (u64)out->guid;
+    return (g >= r->first && g < r->first + r->n) ? 0 : OCR_EINVAL;
+}
+u8 ocrGetGuidKind(ocrGuidUserKind *outKind, ocrGuid_t guid) {
+    if (!outKind) return OCR_EINVAL;
+    u32 k = OCRGPU_GUID_KIND((u64)guid.guid);
+    *outKind = (k == 2 || k == 3 || k == 4 || k == 17 || k == 18 || k == 19 || k == 21 || k == 22) ? (ocrGuidUserKind)k : GUID_USER_NONE;
+    return 0;
+}
+
 /* ---- the OCR API -------------------------------------------------------------------------------------------- */
 static u32 evt_guid_kind(ocrEventTypes_t t) {
     switch (t) {
@@ -221,20 +314,21 @@ static u32 evt_guid_kind(ocrEventTypes_t t) {
     }
 }
 u8 ocrEventCreateParams(ocrGuid_t *guid, ocrEventTypes_t type, u16 properties, ocrEventParams_t *params) {
-    (void)properties;
     u32 gk = evt_guid_kind(type);
     if (!guid) return OCR_EINVAL;
     if (!gk) { guid->guid = -1; return OCR_ENOTSUP; } /* CHANNEL: s8f item 3, not on the engine yet */
     if (type == OCR_EVENT_COUNTED_T && (!params || params->EVENT_COUNTED.nbDeps == 0 || params->EVENT_COUNTED.nbDeps > 0xFFFF)) { guid->guid = -1; return OCR_EINVAL; }
+    u64 lg; u8 lr = labeled_guid(guid, properties, gk, C_EVT_CREATE, &lg);
+    if (lr) return lr;
     Op *o = emit(C_EVT_CREATE);
-    o->a = pool_take(gk); o->slot = (u32)type;
+    o->a = lg ? lg : pool_take(gk); o->slot = (u32)type;
     o->arg = (type == OCR_EVENT_LATCH_T && params) ? (s32)params->EVENT_LATCH.counter        /* hc-event.c:1579-1589 */
            : type == OCR_EVENT_COUNTED_T ? (s32)params->EVENT_COUNTED.nbDeps : 0;            /* hc-event.c:1600-1612 */
     guid->guid = (intptr_t)o->a;
     return 0;
 }
 u8 ocrEventCreate(ocrGuid_t *guid, ocrEventTypes_t type, u16 properties) { return ocrEventCreateParams(guid, type, properties, NULL); }
-u8 ocrEventDestroy(ocrGuid_t guid) { Op *o = emit(C_EVT_DESTROY); o->a = (u64)guid.guid; return 0; }
+u8 ocrEventDestroy(ocrGuid_t guid) { Op *o = emit(C_EVT_DESTROY); o->a = (u64)guid.guid; labset_release(o->a); return 0; }
 u8 ocrEventSatisfySlot(ocrGuid_t evt, ocrGuid_t db, u32 slot) {
     if (ocrGuidIsNull(evt)) return 0; /* ocr-edt.c:171 */
     emit_satisfy((u64)evt.guid, (u64)db.guid, slot);
@@ -250,16 +344,18 @@ u8 ocrAddDependence(ocrGuid_t src, ocrGuid_t dst, u32 slot, ocrDbAccessMode_t mo
 u8 ocrDbCreate(ocrGuid_t *db, void **addr, u64 len, u16 flags, ocrHint_t *hint, ocrInDbAllocator_t allocator) {
     (void)hint; (void)allocator;
     if (!db || !addr) return OCR_EINVAL;
+    u64 lg; u8 lr = labeled_guid(db, flags, OCRGPU_KIND_DB, C_DB_CREATE, &lg);
+    if (lr) return lr;
     void *p = calloc(1, len ? len : 1);
     if (!p) return OCR_ENOMEM;
     Op *o = emit(C_DB_CREATE);
-    o->a = pool_take(OCRGPU_KIND_DB); o->b = (u64)(uintptr_t)p;
+    o->a = lg ? lg : pool_take(OCRGPU_KIND_DB); o->b = (u64)(uintptr_t)p;
     dbmap_put(o->a, p);
     db->guid = (intptr_t)o->a; *addr = (flags & DB_PROP_NO_ACQUIRE) ? NULL : p; /* ocr-db.h:60-64 */
     return 0;
 }
 u8 ocrDbRelease(ocrGuid_t db) { (void)db; return 0; } /* payloads are plain host memory: nothing to write back */
-u8 ocrDbDestroy(ocrGuid_t db) { Op *o = emit(C_DB_DESTROY); o->a = (u64)db.guid; return 0; }
+u8 ocrDbDestroy(ocrGuid_t db) { Op *o = emit(C_DB_DESTROY); o->a = (u64)db.guid; labset_release(o->a); return 0; }
 
 u8 ocrEdtTemplateCreate_internal(ocrGuid_t *guid, ocrEdt_t fn, u32 paramc, u32 depc, const char *name) {
     (void)name;
@@ -307,7 +403,13 @@ u8 ocrEdtCreate(ocrGuid_t *guid, ocrGuid_t tplGuid, u32 paramc, u64 *paramv, u32
     memset(t, 0, sizeof *t);
     t->fn = tp->fn; t->paramc = paramc; t->depc = depc;
     if (paramc) { t->paramv = xrealloc(NULL, 8 * (size_t)paramc); memcpy(t->paramv, paramv, 8 * (size_t)paramc); }
-    t->guid = pool_take(OCRGPU_KIND_EDT);
+    u64 lg = 0;
+    if (props & GUID_PROP_IS_LABELED) { /* the EDT is created at *guid; depv is ignored (ocr-edt.c:323-330) */
+        u8 lr = guid ? labeled_guid(guid, props, OCRGPU_KIND_EDT, C_EDT_CREATE, &lg) : OCR_EINVAL;
+        if (lr) { free(t->paramv); --n_task; return lr; }
+        depv = NULL;
+    }
+    t->guid = lg ? lg : pool_take(OCRGPU_KIND_EDT);
     /* EDT_PROP_OEVT_VALID (ocr-edt.c:378-386, hc-task.c:940-959): the caller's own event takes the place of the ONCE */
     const int own_evt = (props & EDT_PROP_OEVT_VALID) && outputEvent && outputEvent->guid != 0 && outputEvent->guid != -1 && outputEvent->guid != -2;
     if ((props & EDT_PROP_OEVT_VALID) && !own_evt) { --n_task; return OCR_EINVAL; }

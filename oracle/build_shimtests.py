@@ -21,7 +21,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = "/root/reference/ocr"
 TESTS = os.path.join(REF, "tests", "non-regression-tests")
-DIRS = ["events", "finish", "edt", "datablock"]
+DIRS = ["events", "finish", "edt", "datablock", "guidlabel"]
+ARGS = {"testGuidLabelFib": ["12"]}          # command-line arguments a program needs
+# programs whose console lines depend on which of two concurrent EDTs wins a labeled create: only exit code and
+# PASSED/FAILURE lines are compared
+LOOSE_DIRS = {"guidlabel"}
 OUT_REF = os.path.join(HERE, "_ref", "reftests")
 OUT_SHIM = os.path.join(HERE, "_ref", "shimtests")
 FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_programs.json")
@@ -44,7 +48,7 @@ def build_ref(src, out):
 
 def build_shim(src, out):
     cmd = ["gcc", "-O1", "-w", "-std=gnu11", "-DENABLE_EXTENSION_PARAMS_EVT", "-DENABLE_EXTENSION_COUNTED_EVT",
-           "-I", os.path.join(ROOT, "include", "ocr_shim"), "-I", os.path.join(ROOT, "include"),
+           "-DENABLE_EXTENSION_LABELING", "-I", os.path.join(ROOT, "include", "ocr_shim"), "-I", os.path.join(ROOT, "include"),
            src, os.path.join(ROOT, "ocr_amd", "libocrshim.a"), "-L", os.path.join(ROOT, "ocr_amd"), "-locrgpu",
            "-Wl,-rpath,$ORIGIN/../../../ocr_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", out]
     return subprocess.run(cmd, capture_output=True, text=True).returncode == 0
@@ -65,6 +69,8 @@ def main():
         from oracle import mkcfg
         cfg = os.path.join(OUT_REF, "hc-1w.cfg")
         open(cfg, "w").write(mkcfg.cfg(1))
+        cfg_lab = os.path.join(OUT_REF, "hc-1w-labeled.cfg")     # guidReserve needs the LABELED provider (counted-map-guid.c:207)
+        open(cfg_lab, "w").write(mkcfg.cfg(1, guid="LABELED"))
     n_shim = 0
     for src in sources():
         name = os.path.splitext(os.path.basename(src))[0]
@@ -75,10 +81,12 @@ def main():
             if name in old["programs"]:
                 fixture["programs"][name] = dict(old["programs"][name], shim_builds=has_shim)
             continue
-        ent = {"source": rel, "shim_builds": has_shim}
+        ent = {"source": rel, "shim_builds": has_shim, "args": ARGS.get(name, []),
+               "compare": "verdict-lines" if os.path.basename(os.path.dirname(src)) in LOOSE_DIRS else "all-lines"}
         if build_ref(src, os.path.join(OUT_REF, name)):
             try:
-                r = subprocess.run([os.path.join(OUT_REF, name), "-ocr:cfg", cfg], capture_output=True, text=True, timeout=30)
+                use = cfg_lab if os.path.basename(os.path.dirname(src)) == "guidlabel" else cfg
+                r = subprocess.run([os.path.join(OUT_REF, name), "-ocr:cfg", use] + ARGS.get(name, []), capture_output=True, text=True, timeout=30)
                 ent["rc"], ent["stdout"] = r.returncode, r.stdout.splitlines()
             except subprocess.TimeoutExpired:
                 ent["rc"], ent["stdout"] = "timeout", []

@@ -25,11 +25,16 @@ def test_reference_program(name):
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/shimtests not built (python oracle/build_shimtests.py)")
     want = FIX[name]
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    r = subprocess.run([exe] + list(want.get("args", [])), capture_output=True, text=True, timeout=60)
     if want["rc"] == 0:
         assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
         norm = lambda lines: sorted(re.sub(r"0x[0-9a-fA-F]+", "0xGUID", ln) for ln in lines)  # guid VALUES differ between runtimes
-        assert norm(r.stdout.splitlines()) == norm(want["stdout"]), (r.stdout[-800:], want["stdout"][-10:])
+        got, exp = r.stdout.splitlines(), want["stdout"]
+        if want.get("compare") == "verdict-lines":   # which EDT wins a labeled create is a race in the program itself
+            keep = lambda lines: [ln for ln in lines if ln.startswith(("PASSED", "FAILURE"))]
+            got, exp = keep(got), keep(exp)
+            assert not any(ln.startswith("FAILURE") for ln in got), got
+        assert norm(got) == norm(exp), (r.stdout[-800:], want["stdout"][-10:])
     else:  # programs the reference rejects (asserts): the shim must not report success either
         assert r.returncode != 0, (r.stdout[-500:], r.stderr[-500:])
 
