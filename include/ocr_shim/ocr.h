@@ -62,9 +62,20 @@ static inline bool ocrGuidIsLt(ocrGuid_t a, ocrGuid_t b) { return a.guid < b.gui
 #define GUIDFS(g) GUIDA(g)
 #define GUIDFL(g) GUIDA(g)
 
-/* ---- hints: accepted and ignored (ocr/inc/ocr-types.h:36,404-413) ---- */
-typedef struct { u64 opaque[8]; } ocrHint_t;
+/* ---- hints: kept in the caller's struct, never acted on (ocr/inc/ocr-types.h:36,346-413) ---- */
+typedef enum { OCR_HINT_UNDEF_T, OCR_HINT_EDT_T, OCR_HINT_DB_T, OCR_HINT_EVT_T, OCR_HINT_GROUP_T } ocrHintType_t;
+typedef enum {
+    OCR_HINT_EDT_PROP_START, OCR_HINT_EDT_PRIORITY, OCR_HINT_EDT_SLOT_MAX_ACCESS, OCR_HINT_EDT_AFFINITY, OCR_HINT_EDT_DISPERSE,
+    OCR_HINT_EDT_SPACE, OCR_HINT_EDT_TIME, OCR_HINT_EDT_STATS_HW_CYCLES, OCR_HINT_EDT_STATS_L1_HITS, OCR_HINT_EDT_STATS_L1_MISSES,
+    OCR_HINT_EDT_STATS_FLOAT_OPS, OCR_HINT_EDT_PROP_END,
+    OCR_HINT_DB_PROP_START, OCR_HINT_DB_AFFINITY, OCR_HINT_DB_NEAR, OCR_HINT_DB_INTER, OCR_HINT_DB_FAR, OCR_HINT_DB_HIGHBW, OCR_HINT_DB_PROP_END,
+    OCR_HINT_EVT_PROP_START, OCR_HINT_EVT_PROP_END, OCR_HINT_GROUP_PROP_START, OCR_HINT_GROUP_PROP_END
+} ocrHintProp_t;
+typedef uint64_t ocrHintVal_t;
+typedef struct { ocrHintType_t type; u64 propMask; u64 args[OCR_HINT_GROUP_PROP_END + 1]; } ocrHint_t;
 #define NULL_HINT ((ocrHint_t *)0x0)
+#define OCR_HINT_EDT_DISPERSE_FAR 0
+#define OCR_HINT_EDT_DISPERSE_NEAR 1
 
 /* ---- datablocks (ocr/inc/ocr-types.h:120-174, ocr/inc/ocr-db.h:78-128) ---- */
 typedef enum { NO_ALLOC = 0 } ocrInDbAllocator_t;
@@ -111,6 +122,7 @@ typedef enum { OCR_EVENT_LATCH_DECR_SLOT = 0, OCR_EVENT_LATCH_INCR_SLOT = 1 } oc
 #define EVT_PROP_TAKES_ARG ((u16)0x1)
 typedef struct { u64 counter; } ocrEventLatchParams_t;
 typedef struct { u64 nbDeps; } ocrEventCounterParams_t;
+#define EVENT_CHANNEL_UNBOUNDED ((u32)-1)
 typedef struct { u32 maxGen, nbSat, nbDeps; } ocrEventChannelParams_t;
 typedef struct {
     union {
@@ -146,6 +158,11 @@ void _ocrAssert(bool val, const char *str, const char *file, u32 line);
 #define OCR_ENOMEM 12
 #define OCR_ENOTSUP 95
 #define OCR_EGUIDEXISTS 100
+#define OCR_ENOENT 2
+#define OCR_EPERM 1
+#define OCR_EACCES 13
+#define OCR_EBUSY 16
+#define OCR_ECANCELED 125
 
 /* labeled creation (ocr/inc/ocr-types.h:503-520): the guid passed in names the object to create */
 #define GUID_PROP_NONE ((u16)0x0)

@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = "/root/reference/ocr"
 TESTS = os.path.join(REF, "tests", "non-regression-tests")
-DIRS = ["events", "finish", "edt", "datablock", "guidlabel"]
+DIRS = ["events", "finish", "edt", "datablock", "guidlabel", "dist", "lifecycle"]
 ARGS = {"testGuidLabelFib": ["12"]}          # command-line arguments a program needs
 # programs whose console lines depend on which of two concurrent EDTs wins a labeled create: only exit code and
 # PASSED/FAILURE lines are compared
@@ -31,6 +31,14 @@ OUT_SHIM = os.path.join(HERE, "_ref", "shimtests")
 FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_programs.json")
 APP_DEFS = ["-DENABLE_EXTENSION_PARAMS_EVT", "-DENABLE_EXTENSION_COUNTED_EVT", "-DENABLE_EXTENSION_CHANNEL_EVT",
             "-DENABLE_EXTENSION_RTITF", "-DENABLE_EXTENSION_LABELING", "-DENABLE_EXTENSION_AFFINITY", "-DOCR_ASSERT"]
+
+
+def args_of(src, name):
+    """command-line arguments: ARGS, or the <name>.args file the reference keeps next to the program"""
+    if name in ARGS:
+        return ARGS[name]
+    f = os.path.splitext(src)[0] + ".args"
+    return open(f).read().split() if os.path.exists(f) else []
 
 
 def sources():
@@ -48,7 +56,7 @@ def build_ref(src, out):
 
 def build_shim(src, out):
     cmd = ["gcc", "-O1", "-w", "-std=gnu11", "-DENABLE_EXTENSION_PARAMS_EVT", "-DENABLE_EXTENSION_COUNTED_EVT",
-           "-DENABLE_EXTENSION_LABELING", "-I", os.path.join(ROOT, "include", "ocr_shim"), "-I", os.path.join(ROOT, "include"),
+           "-DENABLE_EXTENSION_LABELING", "-DENABLE_EXTENSION_AFFINITY", "-DENABLE_EXTENSION_CHANNEL_EVT", "-I", os.path.join(ROOT, "include", "ocr_shim"), "-I", os.path.join(ROOT, "include"),
            src, os.path.join(ROOT, "ocr_amd", "libocrshim.a"), "-L", os.path.join(ROOT, "ocr_amd"), "-locrgpu",
            "-Wl,-rpath,$ORIGIN/../../../ocr_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", out]
     return subprocess.run(cmd, capture_output=True, text=True).returncode == 0
@@ -81,12 +89,12 @@ def main():
             if name in old["programs"]:
                 fixture["programs"][name] = dict(old["programs"][name], shim_builds=has_shim)
             continue
-        ent = {"source": rel, "shim_builds": has_shim, "args": ARGS.get(name, []),
+        ent = {"source": rel, "shim_builds": has_shim, "args": args_of(src, name),
                "compare": "verdict-lines" if os.path.basename(os.path.dirname(src)) in LOOSE_DIRS else "all-lines"}
         if build_ref(src, os.path.join(OUT_REF, name)):
             try:
                 use = cfg_lab if os.path.basename(os.path.dirname(src)) == "guidlabel" else cfg
-                r = subprocess.run([os.path.join(OUT_REF, name), "-ocr:cfg", use] + ARGS.get(name, []), capture_output=True, text=True, timeout=30)
+                r = subprocess.run([os.path.join(OUT_REF, name), "-ocr:cfg", use] + args_of(src, name), capture_output=True, text=True, timeout=30)
                 ent["rc"], ent["stdout"] = r.returncode, r.stdout.splitlines()
             except subprocess.TimeoutExpired:
                 ent["rc"], ent["stdout"] = "timeout", []
