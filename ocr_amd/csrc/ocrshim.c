@@ -11,10 +11,10 @@
  * API calls made inside a body are DEFERRED, the execution model the reference implements behind
  * ENABLE_OCR_API_DEFERRABLE (hc-policy.c:1523-1720, hc-task.c:1672-1698): the call returns at once (guids come from
  * blocks reserved with ocrgpu_guid_reserve), is queued, and takes effect when the EDT has returned.  The queue is
- * flushed as batched C-ABI calls.  Program order INSIDE one EDT is kept: every op carries a round number that grows
- * whenever the EDT issues an op of an earlier class than its previous one (classes: event create, DB create, EDT
- * create, add-dependence, satisfy, event destroy, DB destroy) or touches the same event twice in a way that does not
- * commute; the flush runs round by round, class by class.  Order BETWEEN EDTs of one level is not defined by OCR
+ * flushed as batched C-ABI calls.  Program order INSIDE one EDT is kept where it can matter: every op carries a round
+ * number; creates (event, DB, EDT) join the create phase of the current round, and the round grows whenever the EDT
+ * issues an add-dependence / satisfy / event destroy / DB destroy of an earlier class than its previous such call, or
+ * touches the same event twice in a way that does not commute; the flush runs round by round, class by class.  Order BETWEEN EDTs of one level is not defined by OCR
  * (they run concurrently in the reference).
  *
  * Finish EDTs (EDT_PROP_FINISH) follow hc-task.c:1071-1078,1917-1986,1788-1831: a LATCH (counter 1) per finish scope,
@@ -118,8 +118,13 @@ static void body_begin(Task *t) {
     cur_scope = t ? (t->own_latch ? t->own_latch : t->scope_latch) : 0;
 }
 static Op *emit(int cls) {
-    if (cls < cur_cls) { ++cur_round; n_touched = 0; }
-    cur_cls = cls;
+    /* creates introduce new names and depend on nothing issued before them, so they join the current round's create
+     * phase (which runs first) however late they are issued; only the order among add-dependence / satisfy / destroy
+     * calls can matter, and an earlier class after a later one opens a new round */
+    if (cls > C_EDT_CREATE) {
+        if (cls < cur_cls) { ++cur_round; n_touched = 0; }
+        cur_cls = cls;
+    }
     GROW(ops, n_ops, cap_ops);
     Op *o = &ops[n_ops++];
     memset(o, 0, sizeof *o);
@@ -129,10 +134,12 @@ static Op *emit(int cls) {
 static void emit_satisfy(u64 evt, u64 db, u32 slot) {
     /* two satisfies of one event by one EDT keep their order unless they commute (same latch slot) */
     const int latch = OCRGPU_GUID_KIND(evt) == OCRGPU_KIND_EVT_LATCH;
-    for (size_t i = 0; i < n_touched; ++i)
-        if (touched[i].evt == evt && !(latch && touched[i].slot == slot)) { ++cur_round; n_touched = 0; cur_cls = -1; break; }
+    if (!(n_touched && latch && touched[n_touched - 1].evt == evt && touched[n_touched - 1].slot == slot && n_touched == 1))
+        for (size_t i = 0; i < n_touched; ++i)
+            if (touched[i].evt == evt && !(latch && touched[i].slot == slot)) { ++cur_round; n_touched = 0; cur_cls = -1; break; }
     Op *o = emit(C_SATISFY);
     o->a = evt; o->b = db; o->slot = slot;
+    if (n_touched && touched[n_touched - 1].evt == evt && touched[n_touched - 1].slot == slot) return; /* 200k check-ins of one scope: one entry */
     GROW(touched, n_touched, cap_touched);
     touched[n_touched].evt = evt; touched[n_touched].slot = slot; ++n_touched;
 }
@@ -246,7 +253,7 @@ static int labset_add(u64 g, int cls) {
         return 0;
     }
     if (labset[h] != g) { labset[h] = g; ++labset_n; }
-    labalive[h] = 1; labround[h] = ((cur_round + (cls < cur_cls ? 1u : 0u)) << 3) | (u32)cls; labepoch[h] = flush_epoch; /* where emit(cls) will put it */
+    labalive[h] = 1; labround[h] = (cur_round << 3) | (u32)cls; labepoch[h] = flush_epoch; /* where emit(cls) will put it */
     return 1;
 }
 static void labset_release(u64 g) { if (labset_cap) { size_t h = labset_find(g); if (labset[h] == g) labalive[h] = 0; } }

@@ -62,6 +62,45 @@ def build_shim(src, out):
     return subprocess.run(cmd, capture_output=True, text=True).returncode == 0
 
 
+# ---- the reference's own end-to-end micro-benchmarks (performance-tests/ocr/edtExecute*Sync.c: "TIME: completion of
+#      all tasks"), built against both runtimes; tests/test_gpu_reference_perf_programs.py runs them side by side ----
+PERF_DIR = os.path.join(REF, "tests", "performance-tests")
+PERF = {  # program -> -D overrides of performance-tests/defaults.mk
+    "edtExecuteHierFinishSync": {"TREE_DEPTH": 16, "NODE_FANOUT": 2, "LEAF_FANOUT": 10},
+    "edtExecuteFlatFinishSync": {"NB_INSTANCES": 200000},
+    "edtExecuteLatchSync": {"NB_INSTANCES": 200000},
+    "edtExecuteStickySync": {"NB_INSTANCES": 200000},
+}
+PERF_DEFAULTS = {"DB_NBS": 32, "NB_EVT_COUNTED_DEPS": 4, "NB_ITERS": 1000, "NB_INSTANCES": 1000, "DEPV_SZ": 10, "PARAMC_SZ": 2,
+                 "FAN_OUT": 100, "DB_SZ": 4, "NODE_FANOUT": 2, "LEAF_FANOUT": 10, "TREE_DEPTH": 8, "DB_NB_ELT": 10, "DB_TYPE": "u64",
+                 "NB_WORKERS": 1, "NB_NODES": 1}
+OUT_PERF = os.path.join(HERE, "_ref", "perfprogs")
+
+
+def build_perf():
+    os.makedirs(OUT_PERF, exist_ok=True)
+    helper = os.path.join(PERF_DIR, "platform", "x86.c")        # get_time / summary_throughput_timer (gettimeofday)
+    built = []
+    for name, over in PERF.items():
+        src = os.path.join(PERF_DIR, "ocr", name + ".c")
+        defs = [f"-D{k}={v}" for k, v in dict(PERF_DEFAULTS, **over).items()]
+        inc = ["-I", os.path.join(PERF_DIR, "inc")]
+        ref = ["gcc", "-O2", "-w", "-std=gnu11"] + APP_DEFS[:-1] + defs + inc + ["-I", os.path.join(REF, "inc"),
+               "-I", os.path.join(REF, "build", "x86"), src, helper, os.path.join(HERE, "_ref", "libocr_x86_perf.a"), "-lpthread", "-lm",
+               "-o", os.path.join(OUT_PERF, name + "_ref")]
+        shim = ["gcc", "-O2", "-w", "-std=gnu11", "-DENABLE_EXTENSION_PARAMS_EVT", "-DENABLE_EXTENSION_COUNTED_EVT",
+                "-DENABLE_EXTENSION_AFFINITY"] + defs + inc + ["-I", os.path.join(ROOT, "include", "ocr_shim"),
+                "-I", os.path.join(ROOT, "include"), src, helper, os.path.join(ROOT, "ocr_amd", "libocrshim.a"),
+                "-L", os.path.join(ROOT, "ocr_amd"), "-locrgpu", "-lm", "-Wl,-rpath,$ORIGIN/../../../ocr_amd",
+                "-Wl,-rpath-link,/opt/rocm/lib", "-o", os.path.join(OUT_PERF, name + "_shim")]
+        ok = [subprocess.run(c, capture_output=True, text=True).returncode == 0 for c in (ref, shim)]
+        built.append((name, ok))
+    from oracle import mkcfg
+    for w in (1, 8):
+        open(os.path.join(OUT_PERF, f"hc-{w}w.cfg"), "w").write(mkcfg.cfg(w, guid="PTR"))
+    return built
+
+
 def main():
     sys.path.insert(0, ROOT)
     from ocr_amd import build as B
@@ -70,6 +109,8 @@ def main():
     os.makedirs(OUT_REF, exist_ok=True)
     os.makedirs(OUT_SHIM, exist_ok=True)
     shim_only = "--shim" in sys.argv
+    for name, ok in build_perf():
+        print(f"perf program {name:32s} ref/shim built: {ok}")
     old = json.load(open(FIXTURE)) if os.path.exists(FIXTURE) else {"programs": {}}
     fixture = {"generated_by": "oracle/build_shimtests.py: reference runtime (oracle/_ref/libocr_x86_dbg.a), 1 HC worker",
                "programs": {}}
