@@ -48,6 +48,9 @@ static void *xrealloc(void *p, size_t n) { void *q = realloc(p, n ? n : 1); if (
 
 static ocrgpu_engine_t *G;
 static int g_shutdown, g_exit_code, g_verbose;
+#include <time.h>
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static double t_sort, t_calls, t_step, t_pop, t_bodies; /* OCRSHIM_VERBOSE: where the wall time went */
 
 /* ---- guid pools: blocks of reserved guids per kind (guidReserve, ocr-guid.h:127-144) ------------------------ */
 enum { POOL_BLOCK = 4096 };
@@ -163,6 +166,22 @@ static int op_cmp(const void *x, const void *y) {
     return a->seq < b->seq ? -1 : (a->seq > b->seq ? 1 : 0); /* issue order */
 }
 
+/* order the queue by (round, class), issue order within: a counting sort (few distinct keys), qsort as a fallback */
+static Op *ops_tmp; static size_t cap_ops_tmp;
+static void sort_ops(void) {
+    u32 max_round = 0;
+    for (size_t i = 0; i < n_ops; ++i) if (ops[i].round > max_round) max_round = ops[i].round;
+    const size_t nkeys = ((size_t)max_round + 1) * N_CLASS;
+    if (nkeys > (1u << 16)) { qsort(ops, n_ops, sizeof *ops, op_cmp); return; }
+    size_t *cnt = calloc(nkeys + 1, sizeof *cnt); if (!cnt) die("out of host memory");
+    for (size_t i = 0; i < n_ops; ++i) ++cnt[(size_t)ops[i].round * N_CLASS + ops[i].cls + 1];
+    for (size_t k = 0; k < nkeys; ++k) cnt[k + 1] += cnt[k];
+    if (cap_ops_tmp < n_ops) { cap_ops_tmp = n_ops + n_ops / 2; ops_tmp = xrealloc(ops_tmp, cap_ops_tmp * sizeof *ops_tmp); }
+    for (size_t i = 0; i < n_ops; ++i) ops_tmp[cnt[(size_t)ops[i].round * N_CLASS + ops[i].cls]++] = ops[i];
+    memcpy(ops, ops_tmp, n_ops * sizeof *ops);
+    free(cnt);
+}
+
 static u64 *bu64[4]; static u32 *bu32[3]; static s32 *bs32; static size_t bcap;
 static void batch_room(size_t n) {
     if (n <= bcap) return;
@@ -176,7 +195,9 @@ static void batch_room(size_t n) {
 static void flush(void) {
     ++flush_epoch;
     if (!n_ops) return;
-    qsort(ops, n_ops, sizeof *ops, op_cmp);
+    double ts0 = now_s();
+    sort_ops();
+    t_sort += now_s() - ts0; ts0 = now_s();
     size_t i = 0;
     while (i < n_ops) {
         size_t j = i;
@@ -219,6 +240,7 @@ static void flush(void) {
         i = j;
     }
     n_ops = 0;
+    t_calls += now_s() - ts0;
 }
 
 /* ---- labeled guids (ocr/src/guid/labeled/labeled-guid.c, ocr/src/api/extensions/ocr-labeling.c) ------------- */
@@ -590,7 +612,9 @@ int ocrshim_run(int argc, char **argv) {
     while (!g_shutdown) {
         flush();
         u64 has_ready = 0, pending = 0;
+        double tt = now_s();
         CHK(ocrgpu_step(G, 1, 0, &has_ready, &pending, NULL));
+        t_step += now_s() - tt; tt = now_s();
         ++levels;
         u64 ne = 0, nd = 0;
         for (;;) {
@@ -603,6 +627,7 @@ int ocrshim_run(int argc, char **argv) {
             if (rc) die("ocrgpu_pop_ready failed (%d): %s", rc, ocrgpu_last_error());
             break;
         }
+        t_pop += now_s() - tt; tt = now_s();
         if (ne == 0) {
             if (has_ready) continue; /* built-in bodies only on this level */
             fprintf(stderr, "ocrshim: no runnable EDT left and ocrShutdown() was not called (%llu EDTs ran)\n", (unsigned long long)bodies);
@@ -626,6 +651,7 @@ int ocrshim_run(int argc, char **argv) {
             free(tasks[p0[i]].paramv); tasks[p0[i]].paramv = NULL;
             ++bodies;
         }
+        t_bodies += now_s() - tt;
     }
     ocrgpu_stats_t st; memset(&st, 0, sizeof st);
     CHK(ocrgpu_get_stats(G, &st));
@@ -635,6 +661,9 @@ int ocrshim_run(int argc, char **argv) {
                 (unsigned long long)levels, (unsigned long long)bodies, (unsigned long long)st.edt_sat, (unsigned long long)st.evt_sat,
                 (unsigned long long)st.err[0], (unsigned long long)st.err[1], (unsigned long long)st.err[2], (unsigned long long)st.err[3],
                 (unsigned long long)st.err[4], (unsigned long long)st.err[5], (unsigned long long)st.err[6]);
+    if (g_verbose)
+        fprintf(stderr, "ocrshim: seconds: bodies %.3f | queue sort %.3f | batched C-ABI calls %.3f | ocrgpu_step %.3f | ocrgpu_pop_ready %.3f\n",
+                t_bodies, t_sort, t_calls, t_step, t_pop);
     if (errs && !g_exit_code) g_exit_code = 73;
     ocrgpu_fini(G);
     return g_exit_code;
