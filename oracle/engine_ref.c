@@ -43,8 +43,10 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_ONCE_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_
 
 typedef struct { uint32_t dst, slot; uint8_t dst_is_evt, mode_null; } waiter_t;
 typedef struct { uint32_t kind, state; int32_t counter; uint32_t data; uint32_t n_w, cap_w; waiter_t *w; } event_t;
-typedef struct { uint32_t depc, cnt; uint64_t slot_base; uint8_t created; } edtst_t;
-typedef struct { uint32_t payload; uint8_t sat, mode_null; } slot_t;
+typedef struct { uint32_t depc, cnt, frontier; uint64_t slot_base; uint8_t created; } edtst_t;
+/* lazy_evt: a persistent event (index+1) named by ocrAddDependence on which the EDT has NOT registered yet: it does
+ * so only when its frontier -- the first pre-slot not yet satisfied -- reaches this slot (hc-task.c:1286-1338,1361-1410) */
+typedef struct { uint32_t payload, lazy_evt; uint8_t sat, mode_null; } slot_t;
 typedef struct { uint32_t idx, slot, payload; uint8_t is_evt, mode_null; } work_t;
 
 typedef struct {
@@ -84,6 +86,22 @@ static void fan_out(eng_t *E, event_t *v, uint32_t payload) {
     }
 }
 
+static void add_waiter(eng_t *E, event_t *v, waiter_t w);
+/* registerOnFrontier -> registerWaiterEventHcPersist / ...Counted (hc-task.c:395-413, hc-event.c:1092-1163,1176-1248):
+ * the EDT becomes a waiter of a STICKY / IDEM / COUNTED event, or is satisfied at once when the event already is */
+static void register_persistent(eng_t *E, uint32_t evt_idx, uint32_t edt, uint32_t slot, uint8_t mode_null) {
+    event_t *v = &E->ev[evt_idx];
+    if (v->state == ST_DESTROYED || v->state == ST_ABSENT) { E->err[ERR_ONCE_LATE_WAITER]++; return; }
+    if (v->state == ST_SAT) {
+        work_t w = { edt, slot, v->data, 0, mode_null };
+        if (v->kind == OCREVT_COUNTED && --v->counter == 0) v->state = ST_DESTROYED; /* the last registration destroys (:1225-1236) */
+        push_work(E, w);
+        return;
+    }
+    waiter_t w = { edt, slot, 0, mode_null };
+    add_waiter(E, v, w);
+}
+
 /* drain the satisfy work stack (depth-first, like the nested processMessage calls of
  * commonSatisfyRegNode hc-event.c:335-367; the order is not observable in the record) */
 static void drain(eng_t *E) {
@@ -96,7 +114,16 @@ static void drain(eng_t *E) {
             if (s->sat) { E->err[ERR_DOUBLE_SLOT]++; continue; }
             s->sat = 1;
             s->payload = (w.mode_null || s->mode_null) ? 0 : w.payload;
-            if (++t->cnt == t->depc) push_ready(E, w.idx);
+            if (++t->cnt == t->depc) { push_ready(E, w.idx); continue; }
+            if (w.slot == t->frontier) { /* advance the frontier over satisfied slots (hc-task.c:1288-1300) ... */
+                int cond = 1;
+                while (t->frontier != t->depc - 1 && cond) { t->frontier++; cond = E->slots[t->slot_base + t->frontier].sat; }
+                slot_t *f = &E->slots[t->slot_base + t->frontier];
+                if (f->lazy_evt && !f->sat) { /* ... and register on the persistent event found there (:1310-1338) */
+                    uint32_t x = f->lazy_evt - 1; f->lazy_evt = 0;
+                    register_persistent(E, x, w.idx, t->frontier, f->mode_null);
+                }
+            }
             continue;
         }
         event_t *v = &E->ev[w.idx];
@@ -144,6 +171,14 @@ static void op_add_dep(eng_t *E, const ocrops_op_t *op) {
     if (sc != OCRREF_EVT && sc != OCRREF_OUTEVT) { E->err[ERR_BAD_OP]++; return; }
     event_t *v = &E->ev[ev_index(E, op->a)];
     if (!dst_is_evt) E->slots[E->ed[dst].slot_base + op->slot].mode_null = mode_null; /* registerSignalerTaskHc :1373 */
+    if (!dst_is_evt && (v->kind == OCREVT_STICKY || v->kind == OCREVT_IDEM || v->kind == OCREVT_COUNTED)) {
+        /* persistent source, EDT destination: register now only on the frontier slot, else when the frontier gets
+         * there (registerSignalerTaskHc :1391-1405) */
+        edtst_t *t = &E->ed[dst];
+        if (op->slot == t->frontier) { register_persistent(E, ev_index(E, op->a), dst, op->slot, mode_null); drain(E); }
+        else E->slots[t->slot_base + op->slot].lazy_evt = ev_index(E, op->a) + 1;
+        return;
+    }
     if (v->state == ST_DESTROYED || v->state == ST_ABSENT) { E->err[ERR_ONCE_LATE_WAITER]++; return; }
     if (v->state == ST_SAT) { /* persistent, already satisfied: immediate satisfy with stored data */
         work_t w = { dst, op->slot, v->data, (uint8_t)dst_is_evt, mode_null };

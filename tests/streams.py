@@ -6,6 +6,8 @@ testOcrEventToEventDeps0.c, testOcrAddDeps*.c, testOcrDepv*.c, testOcrOutputEven
 testOcrEventParam*.c, dist/testDuplicateDeps*.c) as data, so all three executors can run them.
 Every stream is well formed: its outcome does not depend on the schedule.
 """
+import numpy as np
+
 from ocr_amd.opstream import (BODY_FWD0, BODY_HASH, BODY_NOP, EVT_COUNTED, EVT_IDEM, EVT_LATCH, EVT_ONCE, EVT_STICKY,
                               LATCH_DECR, LATCH_INCR, MODE_NULL, MODE_RO, MODE_RW, Builder, cholesky_dag, layered_dag,
                               powerlaw_dag, stencil_dag)
@@ -276,6 +278,125 @@ def wide_fanin():
 SEMANTIC = [latch_decr_then_incr, latch_incr2_decr2, latch_init_counter, once_no_waiters, sticky_early_and_late,
             counted_events, idem_double_satisfy, mode_null_forces_null, db_and_null_sources, event_chain, forward_and_nop,
             destroy_and_unfired, wide_fanin]
+
+
+def random_stream(seed, n=36, eager_safe=False):
+    """A random WELL-FORMED OCR program (no user errors, no payload races): every kind of source on EDT pre-slots
+    (start event, datablocks, NULL_GUID, output events, ONCE / STICKY / IDEM / COUNTED / LATCH events driven by EDT
+    scripts, by main, by other events, or by nobody), inline and overflow pre-slots, all three bodies, all payload
+    kinds.  Used as fuzz input: reference runtime == restatement on every seed.
+    eager_safe=True keeps COUNTED events off pre-slots the EDT's frontier may never reach: the reference registers an
+    EDT on a persistent event only when all earlier pre-slots are satisfied (hc-task.c:1286-1338), the GPU engine
+    registers at ocrAddDependence; the two differ only in whether such a COUNTED event ends up destroyed."""
+    from ocr_amd.opstream import ref_idx
+    rng = np.random.default_rng(0x0C52F000 + seed)
+    b = Builder(f"fuzz_{seed}")
+    start = b.evt(EVT_ONCE)
+    dbs = [b.db(int(rng.integers(1, 1 << 40))) for _ in range(int(rng.integers(1, 5)))]
+    edts = []          # (ref, fires, depc, has_outevt, body)
+    events = []        # dicts: ref, kind, fires, regs, feeds (event->event edges to add at the end), main_sat
+    late = []          # main ops to issue at the very end (event->event dependences, late main satisfies)
+
+    def pick_payload(e_depc, hash_body):
+        k = int(rng.integers(0, 4))
+        if k == 1:
+            return dbs[int(rng.integers(len(dbs)))]
+        if k == 2 and hash_body:
+            return "outdb"
+        if k == 3 and e_depc:
+            return b.depv(int(rng.integers(e_depc)))
+        return 0
+
+    def new_event(driver_pool, gated_only=False, no_counted=False):
+        """Create an explicit event and decide who satisfies it.  Returns its record."""
+        kind = [EVT_ONCE, EVT_STICKY, EVT_IDEM, EVT_COUNTED, EVT_LATCH][int(rng.integers(5))]
+        if no_counted and kind == EVT_COUNTED:
+            kind = EVT_STICKY
+        ev = {"kind": kind, "regs": 0, "fires": False, "ref": None, "gated": True}   # gated: cannot fire before `start`
+        fired = [d for d in driver_pool if d[1]]
+        how = int(rng.integers(0, 10))
+        if kind == EVT_LATCH:
+            k = int(rng.integers(1, 4))
+            drivers = [driver_pool[int(rng.integers(len(driver_pool)))] for _ in range(k)] if driver_pool else []
+            ev["ref"] = b.evt(EVT_LATCH, len(drivers))
+            for d in drivers:                                  # each contributor checks out once (NULL payload)
+                if rng.integers(4) == 0:
+                    b.script_satisfy(d[0], ev["ref"], 0, LATCH_INCR)
+                    b.script_satisfy(d[0], ev["ref"], 0, LATCH_DECR)
+                b.script_satisfy(d[0], ev["ref"], 0, LATCH_DECR)
+            ev["fires"] = bool(drivers) and all(d[1] for d in drivers)
+            return ev
+        ev["ref"] = b.evt(kind, 1 if kind == EVT_COUNTED else 0)
+        if how == 0 or not driver_pool:                        # never satisfied
+            return ev
+        if how <= 2 and kind != EVT_ONCE and not gated_only:   # satisfied by main right away: later waiters are "late"
+            b.satisfy(ev["ref"], dbs[int(rng.integers(len(dbs)))] if rng.integers(2) else 0)
+            ev["fires"] = True
+            ev["gated"] = False
+            return ev
+        if how == 3 and events:                                # fed by another event (added at the end of main)
+            srcs = [x for x in events if x["gated"] or not gated_only]
+            if not srcs:
+                return ev
+            src = srcs[int(rng.integers(len(srcs)))]
+            late.append(("dep", src, ev))
+            src["regs"] += 1
+            ev["fires"] = src["fires"]
+            ev["gated"] = src["gated"]
+            return ev
+        d = driver_pool[int(rng.integers(len(driver_pool)))]   # satisfied by an EDT's script
+        body_hash = (d[4] & 0xFF) == BODY_HASH
+        pay = pick_payload(d[2], body_hash)
+        pay = b.outdb(d[0]) if pay == "outdb" else pay
+        b.script_satisfy(d[0], ev["ref"], pay)
+        if kind == EVT_IDEM and rng.integers(2):               # a second satisfy from the same body is ignored
+            b.script_satisfy(d[0], ev["ref"], 0)
+        ev["fires"] = d[1]
+        return ev
+
+    for i in range(n):
+        depc = int([1, 1, 1, 2, 2, 3, 4, 6, 7, 9][int(rng.integers(10))])   # never 0: such an EDT would run while main still builds
+        body = [BODY_HASH, BODY_HASH, BODY_NOP, BODY_FWD0][int(rng.integers(4))]
+        outevt = bool(rng.integers(5))
+        e = b.edt(depc, body, outevt=outevt)
+        fires = True
+        drivers = [x for x in edts if x[2] > 0]                # a depc==0 EDT runs while main is still building: it drives nothing
+        for k in range(depc):
+            # slot 0 is always gated by `start` (directly or through something that is), so no EDT that others
+            # depend on can run -- on any worker -- before main has finished wiring the program
+            t = int(rng.integers(0, 12)) if k else [0, 0, 5, 9][int(rng.integers(4))]
+            mode = MODE_NULL if rng.integers(4) == 0 else MODE_RO
+            outs = [x for x in edts if x[3] and x[2] > 0]
+            if t <= 1:
+                b.add_dep(start, e, k, mode)
+            elif t == 2:
+                b.add_dep(dbs[int(rng.integers(len(dbs)))], e, k, mode)
+            elif t == 3:
+                b.add_dep(0, e, k, mode)
+            elif t <= 7 and outs:
+                src = outs[int(rng.integers(len(outs)))]
+                b.add_dep(b.out(src[0]), e, k, mode)
+                fires &= src[1]
+            elif t <= 7:
+                b.add_dep(start, e, k, mode)
+            else:
+                nc = eager_safe and k > 0 and not fires         # the frontier may never get here
+                pool = [x for x in events if (x["gated"] or k) and not (nc and x["kind"] == EVT_COUNTED)]
+                ev = pool[int(rng.integers(len(pool)))] if pool and rng.integers(2) else None
+                if ev is None:
+                    ev = new_event(drivers, gated_only=(k == 0), no_counted=nc)
+                    events.append(ev)
+                b.add_dep(ev["ref"], e, k, mode)
+                ev["regs"] += 1
+                fires &= ev["fires"]
+        edts.append((e, fires, depc, outevt, body))
+    for what, src, dst in late:                                # event -> event dependences, after every EDT registration
+        slot = LATCH_DECR if dst["kind"] == EVT_LATCH else 0
+        b.add_dep(src["ref"], dst["ref"], slot, MODE_RO)
+    for ev in events:                                          # COUNTED: nbDeps = the registrations it will see
+        if ev["kind"] == EVT_COUNTED:
+            b.evts[ref_idx(ev["ref"])] = (EVT_COUNTED, max(1, ev["regs"]))
+    return b.finish([x[0] for x in edts if x[1]], start)
 
 
 def all_streams():
