@@ -33,7 +33,8 @@ enum { OCRGPU_HOST = 0, OCRGPU_DEVICE = 1 };
  * ocr/src/inc/ocr-guid.h:127-144; GUID_PROP_IS_LABELED ocr/inc/ocr-types.h:504).  Lets a host shim hand a guid back
  * from ocrEdtCreate at once and create the object later in a batch (deferred API, hc-policy.c:1523-1720).
  * ocrgpu_edt_create: guids_out = EDT guids, outevt_guids_out = output-event guids (kind ONCE; 0 or NULL = none),
- * outdb_guids_out is ignored. */
+ * outdb_guids_out is ignored.  ocrgpu_db_create also takes the guid of ANOTHER location's DB: the entry is then this
+ * engine's copy of that DB (proxy DB, hc-dist-policy.c:382-440), which satisfies issued here carry by value. */
 #define OCRGPU_GUIDS_GIVEN 4
 
 enum {
@@ -123,6 +124,8 @@ int ocrgpu_edt_create(ocrgpu_engine_t *e, uint64_t n, const uint32_t *depc, cons
 /* the satisfies an EDT body performs before returning (its own ocrEventSatisfySlot calls):
  * EDT edt[i] runs ops[begin[i] .. begin[i]+len[i]).  target = event guid; payload_kind selects
  * NULL_GUID / a DB guid in `payload` / the EDT's own output DB / depv[payload].guid            */
+/* The ops of one script apply in order, as the calls of one EDT body do; every op of a level takes effect in that
+ * level's event phase, so a destroy of an event the same script satisfies belongs in a later call, not the script. */
 typedef struct { uint64_t target, payload; uint32_t slot; uint8_t op, payload_kind; uint16_t pad; } ocrgpu_script_op_t;
 enum { OCRGPU_PAY_NULL = 0, OCRGPU_PAY_GUID = 1, OCRGPU_PAY_OUTDB = 2, OCRGPU_PAY_DEPV = 3 };
 enum { OCRGPU_SOP_SATISFY = 5, OCRGPU_SOP_EVT_DESTROY = 6 };
@@ -137,7 +140,13 @@ int ocrgpu_set_hash_tag_base(ocrgpu_engine_t *e, uint64_t tag_base);
 int ocrgpu_add_dependence(ocrgpu_engine_t *e, uint64_t n, const uint64_t *src, const uint64_t *dst,
                           const uint32_t *slot, const uint32_t *mode, int where);
 /* ocrEventSatisfySlot(evt, db, slot) (ocr-edt.c:127).  Takes effect (fan-out through events) at
- * once; EDTs that become ready wait for ocrgpu_resolve / ocrgpu_step.                          */
+ * once; EDTs that become ready wait for ocrgpu_resolve / ocrgpu_step.
+ * For a LATCH, slot is OCR_EVENT_LATCH_DECR_SLOT (0), OCR_EVENT_LATCH_INCR_SLOT (1), or OCRGPU_LATCH_DELTA(k): the net
+ * of k INCRs (k > 0) or -k DECRs the caller made in a row, applied as one op (the latch fires if it leaves 0; k = 0
+ * is an INCR followed by a DECR).  The satisfies of one call are applied concurrently: a caller whose ops on one
+ * latch must keep their order (INCR before DECR) passes their net.                                                */
+#define OCRGPU_LATCH_DELTA_BIAS 0x40000000u
+#define OCRGPU_LATCH_DELTA(k) ((uint32_t)(OCRGPU_LATCH_DELTA_BIAS + (int32_t)(k)))
 int ocrgpu_event_satisfy_slot(ocrgpu_engine_t *e, uint64_t n, const uint64_t *evt, const uint64_t *db,
                               const uint32_t *slot, int where);
 /* ocrEventDestroy (ocr-edt.c:101) */

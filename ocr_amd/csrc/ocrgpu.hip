@@ -45,6 +45,9 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_
 #define RF_PIECE 32u    // record only: fan out piece `slot` (BIG_ROW edges) of the fired event's row
 #define INLINE_SLOTS 6u
 #define BODY_F_SCRIPT 0x10000u // internal: EDT has a script
+#define SCRIPT_F_LATCH 0x20000u // internal: a script op that satisfies a LATCH (0x10000 = the target is remote)
+#define SCRIPT_F_IDEM 0x40000u  // internal: a script op that satisfies an IDEM event
+#define SOP_MERGED 0u           // internal: script op folded into an earlier one
 
 // One explicit event = 16 B: CSR row of its waiters (rebuilt by seal) + state | kind<<8 + LATCH counter /
 // persistent payload.
@@ -246,15 +249,23 @@ __device__ __forceinline__ bool evt_satisfy_simple(const Dev &d, u32 x, u32 kind
 // satisfyEventHcLatch (hc-event.c:812-868) for every latch record held by this wave: lanes that hit the
 // same latch are grouped (readfirstlane + ballot) and ONE atomic applies their summed +1/-1; the group
 // fires iff the counter it leaves is 0 (well-formed programs never pass through 0 before their last op).
+// A slot above 1 is OCRGPU_LATCH_DELTA(k): the net of several ops one caller made in a row (k may be 0).
 __device__ __forceinline__ bool latch_group(const Dev &d, bool is_latch, u32 x, u32 slot) {
     bool fire = false;
     u64 todo = __ballot(is_latch);
+    const u64 general = __ballot(is_latch && slot > 1u);
     while (todo) {
         int leader = __ffsll((long long)todo) - 1;
         u32 x0 = __shfl(x, leader);
         u64 grp = __ballot(is_latch && x == x0) & todo;
         u64 inc = __ballot(is_latch && x == x0 && slot == OCRLATCH_INCR) & todo;
-        s32 delta = (s32)__popcll(inc) - (s32)__popcll(grp & ~inc);
+        u64 gen = grp & general;
+        s32 delta = (s32)__popcll(inc) - (s32)__popcll(grp & ~inc & ~gen);
+        while (gen) { // wave-uniform, rare
+            int b = __ffsll((long long)gen) - 1;
+            delta += (s32)(__shfl(slot, b) - OCRGPU_LATCH_DELTA_BIAS);
+            gen &= gen - 1;
+        }
         if ((int)lane_id() == leader) {
             s32 old = atomicAdd(evt_val(d, x0), delta); // no state read in front of it: one hop, not two
             if (old + delta == 0) {
@@ -498,6 +509,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                     for (u32 k = 0; k < sn; ++k) {
                         Script sc = d.scripts[sb + k];
                         u32 op = sc.op_kind & 0xFF, pk = (sc.op_kind >> 8) & 0xFF;
+                        if (op == SOP_MERGED) continue; // a latch op folded into an earlier one (k_script_merge_latch)
                         if (op == OCRGPU_SOP_SATISFY) {
                             u32 pay = pk == OCRGPU_PAY_GUID ? sc.payload : pk == OCRGPU_PAY_OUTDB ? d.max_db + e + 1
                                     : pk == OCRGPU_PAY_DEPV ? (sl[sc.payload] & 0x7FFFFFFFu) : 0u;
@@ -652,7 +664,9 @@ __global__ void k_db_create(Dev d, u64 n, const u64 *value, const u64 *tag, u32 
     u32 x = first_idx + (u32)i;
     d.db[x] = make_ulonglong2(value[i], tag ? tag[i] : (u64)x);
     u64 g = gin ? gin[i] : mkguid(d.location, OCRGPU_KIND_DB, first_counter + i);
-    if (gin && !given_ok(d, g, OCRGPU_KIND_DB)) return;
+    // a given DB guid may name another policy domain's DB: this entry is then the local copy of it that satisfies
+    // issued here carry by value (the proxy DBs of the reference's distributed PD, hc-dist-policy.c:382-440)
+    if (gin && (OCRGPU_GUID_KIND(g) != OCRGPU_KIND_DB || OCRGPU_GUID_COUNTER(g) == 0)) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
     gtab_put(d, g, (u64)x + 1);
     if (guids_out) guids_out[i] = g;
 }
@@ -716,7 +730,10 @@ __device__ bool resolve_dst(const Dev &d, u64 g, u32 slot, u32 &idx, u32 &flags,
         return true;
     }
     if (!is_event_kind(k)) return false;
-    flags = 0; slot_out = slot; return slot < (1u << 28);
+    flags = 0; slot_out = slot;
+    if (k == OCRGPU_KIND_EVT_LATCH && slot > 1u) // OCRGPU_LATCH_DELTA(k), |k| < 2^28
+        return slot - (OCRGPU_LATCH_DELTA_BIAS - (1u << 28)) < (1u << 29);
+    return slot < (1u << 28);
 }
 
 // registerWaiterEventHcCounted on a satisfied event (hc-event.c:1211-1238): the registration is counted, the last one
@@ -843,7 +860,45 @@ __global__ void k_script_ops(Dev d, u64 n, const ocrgpu_script_op_t *ops, u32 sc
     }
     u32 pay = (u32)o.payload;
     if (o.payload_kind == OCRGPU_PAY_GUID) { u64 pv = gtab_get(d, o.payload); if (!pv) bad_op(d); pay = (u32)pv; }
-    d.scripts[script_base + i] = Script{(u32)(v - 1), pay, o.slot, (u32)o.op | ((u32)o.payload_kind << 8) | remote};
+    const u32 latch = o.op != OCRGPU_SOP_SATISFY ? 0u : OCRGPU_GUID_KIND(o.target) == OCRGPU_KIND_EVT_LATCH ? SCRIPT_F_LATCH
+                    : OCRGPU_GUID_KIND(o.target) == OCRGPU_KIND_EVT_IDEM ? SCRIPT_F_IDEM : 0u;
+    d.scripts[script_base + i] = Script{(u32)(v - 1), pay, o.slot, (u32)o.op | ((u32)o.payload_kind << 8) | remote | latch};
+}
+// One body's ops on one latch apply in program order in the reference (INCR, DECR, DECR on a counter of 1 ends at 0
+// and fires once); here every queued record of a level is applied concurrently, so a run like that is folded into a
+// single record carrying the net count: same end value, no transient 0 from reordering.  Likewise the first of one
+// body's satisfies of an IDEM event is the one that counts (satisfyEventHcPersistIdem, hc-event.c:569-595): the later
+// ones are dropped here rather than left to race with it.  One thread per script.
+__device__ __forceinline__ s32 latch_slot_delta(u32 slot) {
+    return slot == OCRLATCH_INCR ? 1 : slot == OCRLATCH_DECR ? -1 : (s32)(slot - OCRGPU_LATCH_DELTA_BIAS);
+}
+__global__ void k_script_merge_latch(Dev d, u64 n, const u32 *begin, const u32 *len, u32 script_base) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Script *sc = d.scripts + script_base + begin[i];
+    const u32 m = len[i];
+    for (u32 a = 0; a < m; ++a) {
+        const bool ra = sc[a].op_kind & 0x10000u;
+        const u64 ta = ra ? d.rdst[sc[a].target].guid : (u64)sc[a].target;
+        if (sc[a].op_kind & SCRIPT_F_IDEM) {
+            for (u32 b = a + 1; b < m; ++b)
+                if ((sc[b].op_kind & SCRIPT_F_IDEM) && (bool)(sc[b].op_kind & 0x10000u) == ra &&
+                    (ra ? d.rdst[sc[b].target].guid : (u64)sc[b].target) == ta) sc[b].op_kind = SOP_MERGED;
+            continue;
+        }
+        if (!(sc[a].op_kind & SCRIPT_F_LATCH)) continue;
+        const u32 slot_a = ra ? d.rdst[sc[a].target].slot : sc[a].slot;
+        s32 delta = latch_slot_delta(slot_a);
+        bool merged = false;
+        for (u32 b = a + 1; b < m; ++b) {
+            if (!(sc[b].op_kind & SCRIPT_F_LATCH) || (bool)(sc[b].op_kind & 0x10000u) != ra) continue;
+            const u64 tb = ra ? d.rdst[sc[b].target].guid : (u64)sc[b].target;
+            if (tb != ta) continue;
+            delta += latch_slot_delta(ra ? d.rdst[sc[b].target].slot : sc[b].slot);
+            sc[b].op_kind = SOP_MERGED; merged = true;
+        }
+        if (merged) { if (ra) d.rdst[sc[a].target].slot = OCRGPU_LATCH_DELTA(delta); else sc[a].slot = OCRGPU_LATCH_DELTA(delta); }
+    }
 }
 
 // Apply satisfies received from other partitions: resolve the guid in OUR table, clone the DB into a proxy
@@ -1027,7 +1082,7 @@ struct ocrgpu_engine {
     int device; hipStream_t stream; ocrgpu_config_t cfg; Dev d;
     std::vector<void *> allocs;
     // host mirrors
-    u32 n_edt, n_evt, n_db; u64 n_slots, n_script; u64 counter; u64 edges_upper;
+    u32 n_edt, n_evt, n_db; u64 n_slots, n_script, script_cap; u64 counter; u64 edges_upper;
     bool csr_dirty; u32 q_cap;
     // staging
     char *stage_dev; size_t stage_dev_cap, stage_dev_off; char *stage_host; size_t stage_host_cap;
@@ -1169,7 +1224,8 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.blk_stats, 8 * 4 * MAX_GRID));
     TRY(dalloc(e, (void **)&d.dbg, 8 * (16 + 8 * MAX_GRID)));
     { u64 k = getenv("OCRGPU_STAMP_K") ? (u64)atoll(getenv("OCRGPU_STAMP_K")) : 0; (void)hipMemcpyAsync(&d.dbg[15], &k, 8, hipMemcpyHostToDevice, e->stream); (void)hipStreamSynchronize(e->stream); }
-    TRY(dalloc(e, (void **)&d.scripts, sizeof(Script) * ((size_t)cfg->max_edt + 1024)));
+    e->script_cap = (u64)cfg->max_edt + 1024;
+    TRY(dalloc(e, (void **)&d.scripts, sizeof(Script) * e->script_cap));
     TRY(dalloc(e, (void **)&d.gtab, 16 * (size_t)cap));
     u64 tmpn = n_evt_total > cfg->max_edt ? n_evt_total : cfg->max_edt;
     TRY(dalloc(e, (void **)&e->tmp_a, 4 * (size_t)(tmpn + 4)));
@@ -1414,12 +1470,22 @@ extern "C" int ocrgpu_edt_set_scripts(ocrgpu_engine_t *e, u64 n, const u64 *edt,
     ENTER(e);
     if (n == 0 || n_ops == 0) return 0;
     if (!edt || !begin || !len || !ops) FAIL(OCRGPU_EINVAL, "null array");
-    if (e->n_script + n_ops > (u64)e->cfg.max_edt + 1024) FAIL(OCRGPU_ENOMEM, "script pool (max_edt+1024 ops) exhausted");
+    if (e->n_script + n_ops > e->script_cap) { // the pool starts at max_edt + 1024 ops and doubles when a program needs more
+        u64 cap = e->script_cap * 2 > e->n_script + n_ops ? e->script_cap * 2 : e->n_script + n_ops;
+        Script *bigger = nullptr;
+        if (cap > 0xFFFFFFFFull || hipMalloc((void **)&bigger, sizeof(Script) * cap) != hipSuccess) FAIL(OCRGPU_ENOMEM, "script pool cannot grow");
+        HIPCHK(hipMemcpyAsync(bigger, e->d.scripts, sizeof(Script) * e->n_script, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (void *&p : e->allocs) if (p == (void *)e->d.scripts) p = bigger;
+        (void)hipFree(e->d.scripts);
+        e->d.scripts = bigger; e->script_cap = cap;
+    }
     int r = stage_reserve(e, rup(8 * n) + 2 * rup(4 * n) + rup(sizeof(ocrgpu_script_op_t) * n_ops)); if (r) return r;
     const u64 *de; const u32 *dbg, *dl; const ocrgpu_script_op_t *dops;
     if ((r = stage_in(e, edt, n, where, &de)) || (r = stage_in(e, begin, n, where, &dbg)) || (r = stage_in(e, len, n, where, &dl)) ||
         (r = stage_in(e, ops, n_ops, where, &dops))) return r;
     k_script_ops<<<nblk(n_ops), 256, 0, e->stream>>>(e->d, n_ops, dops, (u32)e->n_script);
+    k_script_merge_latch<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dbg, dl, (u32)e->n_script);
     k_set_scripts<<<nblk(n), 256, 0, e->stream>>>(e->d, n, de, dbg, dl, (u32)e->n_script);
     e->n_script += n_ops;
     HIPCHK(hipGetLastError());

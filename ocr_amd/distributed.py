@@ -12,6 +12,10 @@ Ownership: an object lives on the rank named by its GUID's LOCHOME bits (ocr/src
 """
 from __future__ import annotations
 
+# torch ships its own copy of the HIP runtime: load it before libocrgpu.so pulls in /opt/rocm's, so that one runtime
+# serves both in this process (the other order leaves torch with "No HIP GPUs are available")
+import torch  # noqa: F401
+
 import numpy as np
 
 from . import opstream as ops
@@ -57,7 +61,7 @@ class Partition:
         self.send_cap = cap
         self.send = self.torch.zeros((world, cap, REC_BYTES), dtype=self.torch.uint8, device=f"cuda:{device}")
         self.eng = Engine(max_edt=max(n_my_edt, 1), max_evt=max(int((self.own_evt == rank).sum()), 1),
-                          max_db=max(int((self.own_db == rank).sum()), 1) + world * cap + 16,
+                          max_db=s.n_db + world * cap + 16,
                           max_slots=int(s.edt["depc"][mine_e].sum()) + 1, max_edges=n_adddep + 1, device=device,
                           location=rank, flags=flags)
         self.eng.exchange_config(world, self.send.data_ptr(), cap, n_adddep + len(s.script) + 16)
@@ -217,7 +221,12 @@ class Partition:
         pk, pay = np.zeros(len(sc), np.uint8), np.zeros(len(sc), np.uint64)
         m = cls == ops.REF_DB
         if m.any():
-            assert np.all(self._owner_of_refs(sub["b"][m]) == self.rank), "script payload DB must live with the EDT"
+            # a body may satisfy with a DB that lives on another partition: satisfies carry DBs by value, so this
+            # rank keeps a copy under the DB's own guid (main's DBs never change after creation)
+            away = np.unique(ops.ref_idx(sub["b"][m]).astype(np.int64))
+            away = away[self.own_db[away] != self.rank]
+            if len(away):
+                self.eng.db_create(s.db_init[away], away.astype(np.uint64), guids=self.db_guid[away])
             pk[m], pay[m] = 1, self._guids(sub["b"][m])
         pk[cls == ops.REF_OUTDB] = 2
         m = cls == ops.REF_DEPV

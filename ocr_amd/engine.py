@@ -21,6 +21,13 @@ from .opstream import OpStream, Result
 HOST, DEVICE = 0, 1
 GUIDS_GIVEN = 4   # OR into `where` of the create calls: guid arrays are inputs (ocrgpu.h)
 F_NANNY, F_TIMING = 1, 2
+
+
+def LATCH_DELTA(k):
+    """slot value of one latch op that stands for the net of k INCRs (k < 0: DECRs) -- OCRGPU_LATCH_DELTA (ocrgpu.h)"""
+    return 0x40000000 + int(k)
+
+
 # ocrGuidKind values in the guid KIND bits (ocrgpu.h)
 KIND_DB, KIND_EDT, KIND_EVT_ONCE, KIND_EVT_COUNTED, KIND_EVT_IDEM, KIND_EVT_STICKY, KIND_EVT_LATCH = 2, 3, 17, 18, 19, 21, 22
 _LIB_PATH = os.environ.get("OCRGPU_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libocrgpu.so")

@@ -2,6 +2,7 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  -- before libocrgpu.so: torch's own HIP runtime must be the one loaded first (ocr_amd/distributed.py)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):

@@ -290,7 +290,7 @@ def random_stream(seed, n=36, eager_safe=False):
     registers at ocrAddDependence; the two differ only in whether such a COUNTED event ends up destroyed."""
     from ocr_amd.opstream import ref_idx
     rng = np.random.default_rng(0x0C52F000 + seed)
-    b = Builder(f"fuzz_{seed}")
+    b = Builder(f"fuzz{'_safe' if eager_safe else ''}_{seed}")
     start = b.evt(EVT_ONCE)
     dbs = [b.db(int(rng.integers(1, 1 << 40))) for _ in range(int(rng.integers(1, 5)))]
     edts = []          # (ref, fires, depc, has_outevt, body)
@@ -390,13 +390,24 @@ def random_stream(seed, n=36, eager_safe=False):
                 ev["regs"] += 1
                 fires &= ev["fires"]
         edts.append((e, fires, depc, outevt, body))
-    for what, src, dst in late:                                # event -> event dependences, after every EDT registration
+    # event -> event dependences, after every EDT registration; newest first, so that a destination has all of its
+    # own waiters before a source that main already satisfied fires (and, if ONCE, destroys) it
+    for what, src, dst in reversed(late):
         slot = LATCH_DECR if dst["kind"] == EVT_LATCH else 0
         b.add_dep(src["ref"], dst["ref"], slot, MODE_RO)
     for ev in events:                                          # COUNTED: nbDeps = the registrations it will see
         if ev["kind"] == EVT_COUNTED:
             b.evts[ref_idx(ev["ref"])] = (EVT_COUNTED, max(1, ev["regs"]))
     return b.finish([x[0] for x in edts if x[1]], start)
+
+
+FUZZ_SEEDS = 64        # seeds with a committed reference digest in tests/golden/fuzz.json, per generator flavour
+
+
+def stream_digest(s):
+    """Hash of a stream's op arrays (pins the generator against the committed fuzz goldens)."""
+    from ocr_amd.opstream import fnv1a64
+    return fnv1a64(b"".join(np.ascontiguousarray(getattr(s, f)).tobytes() for f in ("edt", "evt", "db_init", "main", "script")))
 
 
 def all_streams():

@@ -1,0 +1,63 @@
+"""Fuzz pin of the oracle: random well-formed OCR programs (streams.random_stream -- every event kind, every kind
+of source, drivers that never fire, EDTs that stay blocked).  The restatement must reproduce the digest the
+REFERENCE runtime produced for each seed (tests/golden/fuzz.json, written by tests/golden/make_golden.py after
+checking 1 worker == 4 workers), and -- where the reference build is present -- a live run on seeds beyond the
+committed ones."""
+import json
+import os
+
+import pytest
+
+import streams
+from oracle import ref as O
+
+
+@pytest.fixture(scope="module")
+def fuzz(golden_dir):
+    with open(os.path.join(golden_dir, "fuzz.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("safe", [False, True])
+def test_restatement_matches_reference_digests(safe, fuzz):
+    seen_blocked = seen_all = 0
+    for seed in range(streams.FUZZ_SEEDS):
+        s = streams.random_stream(seed, eager_safe=safe)
+        ent = fuzz[s.name]
+        assert f"{streams.stream_digest(s):016x}" == ent["input"], f"{s.name}: generator drifted from the golden input"
+        r, stats = O.run_restatement(s, return_stats=True)
+        assert int(stats[8:].sum()) == 0, f"{s.name}: restatement flagged user errors {stats[8:]}"
+        assert (r.n_fired, f"{r.digest():016x}") == (ent["n_fired"], ent["digest"]), s.name
+        seen_blocked += r.n_fired < s.n_edt
+        seen_all += r.n_fired == s.n_edt
+    assert seen_blocked > 10        # the corpus does exercise EDTs that never fire
+
+
+@pytest.mark.skipif(not O.reference_available(), reason="reference runtime build (oracle/_ref) not present")
+@pytest.mark.parametrize("workers", [1, 4])
+def test_restatement_matches_live_reference_on_fresh_seeds(workers):
+    for seed in range(1000, 1024):
+        s = streams.random_stream(seed, n=48)
+        ref, _ = O.run_reference(s, workers=workers)
+        assert O.run_restatement(s).diff(ref) == [], s.name
+
+
+def test_lazy_frontier_is_visible_in_a_counted_event():
+    """The one place registration order shows in the record (hc-task.c:1286-1338): a COUNTED event on pre-slot 1 of
+    an EDT whose pre-slot 0 is never satisfied keeps its count, because the EDT never registered on it."""
+    from ocr_amd.opstream import (BODY_NOP, EVS_LIVE_SAT, EVT_COUNTED, EVT_ONCE, MODE_RO, Builder)
+    b = Builder("lazy_frontier")
+    start = b.evt(EVT_ONCE)
+    never = b.evt(EVT_ONCE)
+    c = b.evt(EVT_COUNTED, 1)
+    e = b.edt(2, BODY_NOP)
+    b.add_dep(never, e, 0, MODE_RO)
+    b.add_dep(c, e, 1, MODE_RO)
+    b.satisfy(c, 0)
+    ok = b.edt(1, BODY_NOP)
+    b.add_dep(start, ok, 0, MODE_RO)
+    s = b.finish([ok], start)
+    r = O.run_restatement(s)
+    assert r.level[0] == -1 and r.evt_state[2] & 0xFF == EVS_LIVE_SAT
+    if O.reference_available():
+        assert O.run_reference(s)[0].diff(r) == []
