@@ -152,8 +152,14 @@ static void emit_satisfy(u64 evt, u64 db, u32 slot) {
  * this body (hc-task.c:1071-1078) are issued here, before the check-out. */
 static void body_end(Task *t, u64 ret) {
     if (t && !t->own_latch && t->outevt) { Op *d = emit(C_ADD_DEP); d->a = ret; d->b = t->outevt; d->slot = 0; d->mode = DB_MODE_RW; }
-    for (u32 k = 0; k < pending_checkins; ++k) emit_satisfy(cur_scope, 0, OCRLATCH_INCR);
+    const u64 out_latch = !t ? 0 : t->own_latch ? t->own_latch : t->scope_latch;
+    const u32 in = pending_checkins;
     pending_checkins = 0;
+    if (in && out_latch == cur_scope) { /* k check-ins and the check-out hit the same latch: one op with their net */
+        emit_satisfy(cur_scope, t->own_latch ? ret : 0, in == 2 ? OCRLATCH_INCR : OCRGPU_LATCH_DELTA((s32)in - 1));
+        return;
+    }
+    if (in) emit_satisfy(cur_scope, 0, in == 1 ? OCRLATCH_INCR : OCRGPU_LATCH_DELTA((s32)in));
     if (!t) return;
     if (t->own_latch) emit_satisfy(t->own_latch, ret, OCRLATCH_DECR);
     else if (t->scope_latch) emit_satisfy(t->scope_latch, 0, OCRLATCH_DECR);
