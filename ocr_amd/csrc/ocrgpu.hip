@@ -43,7 +43,13 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_
 #define RF_PREFILLED 8u // EDT destination: the payload was already written at registration (static payload)
 #define RF_FIRED 16u    // record only: the event already fired (its satisfy logic ran inline), just fan out
 #define RF_PIECE 32u    // record only: fan out piece `slot` (BIG_ROW edges) of the fired event's row
+#define RF_LAZYWALK 64u // record only: pre-slot `slot` of frontier-tracked EDT `dst` was satisfied -> lazy_walk()
 #define INLINE_SLOTS 6u
+#define SLOT_MARK 0x80000000u  // pre-slot word: the slot has been satisfied
+#define PEND_LAZY 0x40000000u  // EdtLine.pending: a COUNTED event sits on a pre-slot the frontier has not reached -> track the frontier
+#define PEND_MASK 0x3FFFFFFFu
+#define LAZY_FRONT 0xFFFFFFFFu // lazy_tab key slot of an EDT's frontier word
+#define CNT_SAT (1ull << 63)   // counted[]: [satisfied:1 | registrations left:31 | lazy registrations not yet made:32]
 #define BODY_F_SCRIPT 0x10000u // internal: EDT has a script
 #define SCRIPT_F_LATCH 0x20000u // internal: a script op that satisfies a LATCH (0x10000 = the target is remote)
 #define SCRIPT_F_IDEM 0x40000u  // internal: a script op that satisfies an IDEM event
@@ -72,6 +78,8 @@ static_assert(sizeof(SendRec) == 32, "SendRec is 32 bytes");
 #define XF_MODE_NULL 1u
 #define XF_HAS_DB 2u
 #define XF_DESTROY 4u    // ocrEventDestroy of an event owned by another partition
+#define XF_LAZYREG 16u   // guid/slot = an EDT pre-slot here; value = guid of the COUNTED event (there) registered on it
+#define XF_ACTIVATE 32u  // guid = a COUNTED event here: a held-back registration of a remote EDT has now been made
 #define RF_REMOTE 8u     // waiter flag (with bit0 clear): lo = index into rdst[]; bit2 = dst is an EDT, bit1 = MODE_NULL
 struct RemoteDst { u64 guid; u32 slot, flags; };
 
@@ -103,6 +111,8 @@ struct Dev {
     u32 *slots;                 // overflow pre-slot words (depc > 6): dbidx+1 (0 = NULL_GUID); bit31 = satisfied (nanny)
     // events: explicit [0,max_evt) in `evt`; the output event of EDT e is event max_evt+e and lives in edt[e]
     EvtRec *evt;
+    u64 *counted;               // COUNTED events: the accounting word (CNT_SAT | left << 32 | lazy pending), see counted_*()
+    ulonglong2 *lazy_tab; u64 lazy_mask; // (EDT, pre-slot) -> COUNTED event waiting for the frontier; (EDT, LAZY_FRONT) -> frontier
     u64 *waiters;               // CSR payload: lo = dst ; hi = flags<<28 | (pre-slot k of the EDT | latch slot)
     u32 *log_src; u64 *log_rec; // registration log the CSR is built from
     // datablocks (explicit [0,max_db) then the output DB of EDT e at max_db+e): {value, tag}
@@ -192,20 +202,120 @@ __device__ __forceinline__ u32 wave_append(u32 *tail, bool pred) {
 // satisfy primitives
 // ------------------------------------------------------------------------------------------------
 // satisfyTaskHc (hc-task.c:1216-1266): store the payload word, count the slot, report "all satisfied"
+__device__ void emit_remote_raw(const Dev &d, u64 guid, u32 slot, u32 xflags, u64 value, u64 tag);
+struct Step { // per-launch constants, identical in every workgroup
+    u32 mode, r_begin, r_end, q_begin, q_end, r_base, q_base; u32 *cnt_r, *cnt_q;
+};
 template <bool NANNY>
-__device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, u32 edt, u32 slot, u32 payload, u32 flags) {
+__device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, const Step &S, u32 edt, u32 slot, u32 payload, u32 flags) {
     EdtLine *L = &d.edt[edt];
     u32 word = (flags & RF_MODE_NULL) ? 0u : payload;
     // overflow pre-slots (depc > 6): `slot` is relative, the base sits in the line the atomic is about to touch
     u32 *sp = nullptr;
     if (NANNY || !(flags & RF_PREFILLED)) sp = (flags & RF_INLINE) ? &L->slot[slot] : &d.slots[(size_t)L->slot[0] + slot];
     if (NANNY) {
-        u32 old = atomicExch(sp, word | 0x80000000u);
-        if (old & 0x80000000u) { atomicAdd(&d.ctrl->err[ERR_DOUBLE_SLOT], 1u); return false; }
+        u32 old = atomicExch(sp, word | SLOT_MARK);
+        if (old & SLOT_MARK) { atomicAdd(&d.ctrl->err[ERR_DOUBLE_SLOT], 1u); return false; }
     } else if (!(flags & RF_PREFILLED)) {
-        *sp = word;
+        *sp = word | SLOT_MARK;
     }
-    return atomicSub(&L->pending, 1u) == 1u;
+    const u32 old = atomicSub(&L->pending, 1u);
+    if (old & PEND_LAZY) { // rare: this EDT's frontier is tracked (COUNTED accounting); the walk runs in the next EVENTS phase
+        const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
+        if (qi < d.q_cap) d.q[qi] = Rec{edt, 0u, slot, RF_LAZYWALK}; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+    }
+    return (old & PEND_MASK) == 1u;
+}
+
+// ---- COUNTED accounting + lazy frontier registration --------------------------------------------------------
+// The reference registers an EDT on a persistent event at pre-slot k only when pre-slots 0..k-1 are satisfied
+// (iterateDbFrontier / registerOnFrontier, hc-task.c:1286-1338, 395-413; registerSignalerTaskHc :1391-1405).  For
+// STICKY / IDEM sources the order is invisible and the engine registers at ocrAddDependence.  A COUNTED event counts
+// its registrations (registerWaiterEventHcCounted hc-event.c:1176-1248, satisfyEventHcCounted :537-565), so for those
+// the engine keeps the data path eager and makes the COUNT lazy: a registration on a pre-slot the frontier has not
+// reached is entered in lazy_tab and only counted once the EDT's frontier gets there.
+__device__ __forceinline__ u64 lazy_key(u32 edt, u32 slot) { return ((u64)(edt + 1) << 32) | slot; }
+__device__ u64 *lazy_find(const Dev &d, u64 key) {
+    u64 h = (key * 0x9E3779B97F4A7C15ULL) >> 20 & d.lazy_mask;
+    for (u64 probe = 0; probe <= d.lazy_mask; ++probe, h = (h + 1) & d.lazy_mask) {
+        const u64 k = d.lazy_tab[h].x;
+        if (k == key) return (u64 *)&d.lazy_tab[h].y;
+        if (k == 0ULL) return nullptr;
+    }
+    return nullptr;
+}
+__device__ void lazy_insert(const Dev &d, u64 key, u64 val) { // the first insert of a key sets its value
+    u64 h = (key * 0x9E3779B97F4A7C15ULL) >> 20 & d.lazy_mask;
+    for (u64 probe = 0; probe <= d.lazy_mask; ++probe, h = (h + 1) & d.lazy_mask) {
+        u64 old = atomicCAS((unsigned long long *)&d.lazy_tab[h].x, 0ULL, (unsigned long long)key);
+        if (old == 0ULL) { d.lazy_tab[h].y = val; return; }
+        if (old == key) return;
+    }
+    atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+}
+__device__ __forceinline__ void counted_destroyed(const Dev &d, u32 x) { atomicExch(evt_state(d, x), (u32)ST_DESTROYED | (OCREVT_COUNTED << 8)); }
+// a registration made on an already satisfied event is served at once; the last one destroys the event (:1211-1238)
+__device__ __forceinline__ void counted_late_registration(const Dev &d, u32 x) {
+    if (x >= d.max_evt || ((*evt_state(d, x) >> 8) & 0xFF) != OCREVT_COUNTED) return;
+    const u64 o = atomicAdd((unsigned long long *)&d.counted[x], (unsigned long long)-(1ll << 32));
+    if (((o >> 32) & 0x7FFFFFFFu) == 1u) counted_destroyed(d, x);
+}
+// the EDT's frontier has reached a pre-slot whose COUNTED registration was held back: it happens now
+__device__ void counted_activate(const Dev &d, u32 x) {
+    u64 o = atomicAdd((unsigned long long *)&d.counted[x], 0ull);
+    for (;;) {
+        u64 nw = o - 1; // one lazy registration fewer
+        const bool sat = (o & CNT_SAT) != 0;
+        if (sat) nw -= 1ull << 32; // ...and it is served at once
+        const u64 prev = atomicCAS((unsigned long long *)&d.counted[x], (unsigned long long)o, (unsigned long long)nw);
+        if (prev == o) { if (sat && ((nw >> 32) & 0x7FFFFFFFu) == 0u) counted_destroyed(d, x); return; }
+        o = prev;
+    }
+}
+// satisfyEventHcCounted: the registrations made so far (row length minus the held-back ones) are served
+__device__ bool counted_satisfy(const Dev &d, u32 x, u32 payload) {
+    u32 *sk = evt_state(d, x);
+    const u32 old = atomicCAS(sk, (u32)ST_LIVE | (OCREVT_COUNTED << 8), (u32)ST_SAT | (OCREVT_COUNTED << 8));
+    if ((old & 0xFF) != ST_LIVE) { atomicAdd(&d.ctrl->err[(old & 0xFF) == ST_SAT ? ERR_STICKY_RESAT : ERR_DEAD_EVENT], 1u); return false; }
+    *evt_val(d, x) = (s32)payload;
+    const u32 deg = *evt_deg(d, x);
+    u64 o = atomicAdd((unsigned long long *)&d.counted[x], 0ull);
+    for (;;) {
+        const u32 lp = (u32)o, left = (u32)(o >> 32) & 0x7FFFFFFFu;
+        const u32 served = deg > lp ? deg - lp : 0u;
+        if (served > left) atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); // more registrations than nbDeps (assert :553)
+        const u32 nl = left > served ? left - served : 0u;
+        const u64 nw = CNT_SAT | ((u64)nl << 32) | lp;
+        const u64 prev = atomicCAS((unsigned long long *)&d.counted[x], (unsigned long long)o, (unsigned long long)nw);
+        if (prev == o) { if (nl == 0u) counted_destroyed(d, x); return true; }
+        o = prev;
+    }
+}
+// value of a lazy_tab entry: index of a local COUNTED event, or the guid of one on another partition
+__device__ __forceinline__ void lazy_reached(const Dev &d, u64 v) {
+    if (v >> 32) emit_remote_raw(d, v, 0u, XF_ACTIVATE, 0ull, 0ull); else counted_activate(d, (u32)v);
+}
+// A pre-slot of a frontier-tracked EDT was satisfied: mark it where every CU can see it, then move the frontier
+// over every satisfied pre-slot (whoever wins the CAS f -> f+1 has "reached" pre-slot f+1).  Runs in the EVENTS phase
+// after the satisfy (a queued RF_LAZYWALK record), so the hot satisfy path carries one test and no call.  All shared
+// words are read and written with returning device-scope atomics: waves on other XCDs run the same walk concurrently.
+__device__ __forceinline__ void lazy_walk(const Dev &d, u32 edt, u32 slot) {
+    EdtLine *L = &d.edt[edt];
+    const u32 depc = L->depc;
+    u32 *sl = depc <= INLINE_SLOTS ? L->slot : d.slots + L->slot[0];
+    const u32 was = atomicOr(&sl[slot], SLOT_MARK);
+    asm volatile("" ::"v"(was)); // the mark has landed before the frontier is read
+    u64 *F = lazy_find(d, lazy_key(edt, LAZY_FRONT));
+    if (!F) return;
+    u64 f = atomicAdd((unsigned long long *)F, 0ull);
+    while (f < depc) {
+        if (!(atomicOr(&sl[f], 0u) & SLOT_MARK)) break;
+        if (atomicCAS((unsigned long long *)F, (unsigned long long)f, (unsigned long long)(f + 1)) == f && f + 1 < depc) {
+            const u64 *xv = lazy_find(d, lazy_key(edt, (u32)f + 1));
+            if (xv) lazy_reached(d, *xv);
+        }
+        f = atomicAdd((unsigned long long *)F, 0ull);
+    }
 }
 
 // event.satisfy for ONCE / STICKY / IDEM (hc-event.c:437-465, 569-639).  Returns true when the event
@@ -217,28 +327,7 @@ __device__ __forceinline__ bool evt_satisfy_simple(const Dev &d, u32 x, u32 kind
         if ((old & 0xFF) != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u); return false; }
         return true;
     }
-    if (kind == OCREVT_COUNTED) {
-        // satisfyEventHcCounted (hc-event.c:537-565): sticky; nbDeps (bits 16..31 of the state word) drops by the
-        // waiters registered so far -- the row length, exact here because the CSR is sealed before any k_step --
-        // and the event is gone once all nbDeps registrations have been served.
-        const u32 deg = *evt_deg(d, x);
-        u32 old = *sk;
-        for (;;) {
-            if ((old & 0xFF) != ST_LIVE) {
-                atomicAdd(&d.ctrl->err[(old & 0xFF) == ST_SAT ? ERR_STICKY_RESAT : ERR_DEAD_EVENT], 1u);
-                return false;
-            }
-            const u32 cnt = old >> 16;
-            if (deg > cnt) atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); // more registrations than nbDeps (assert :553)
-            const u32 left = cnt > deg ? cnt - deg : 0u;
-            const u32 nw = (left ? (u32)ST_SAT : (u32)ST_DESTROYED) | (kind << 8) | (left << 16);
-            const u32 prev = atomicCAS(sk, old, nw);
-            if (prev == old) break;
-            old = prev;
-        }
-        *evt_val(d, x) = (s32)payload;
-        return true;
-    }
+    if (kind == OCREVT_COUNTED) return counted_satisfy(d, x, payload);
     u32 old = atomicCAS(sk, ST_LIVE | (kind << 8), ST_SAT | (kind << 8));
     if ((old & 0xFF) == ST_LIVE) { *evt_val(d, x) = (s32)payload; return true; }
     if ((old & 0xFF) == ST_SAT) { if (kind == OCREVT_STICKY) atomicAdd(&d.ctrl->err[ERR_STICKY_RESAT], 1u); }
@@ -304,15 +393,16 @@ __device__ __forceinline__ void emit_remote(const Dev &d, u64 guid, u32 slot, u3
     if (d.send == nullptr || loc >= d.n_loc) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
     ulonglong2 b = make_ulonglong2(0, 0);
     if (payload && !(xflags & XF_MODE_NULL)) { b = db_gather(d, payload); xflags |= XF_HAS_DB; }
+    emit_remote_raw(d, guid, slot, xflags, b.x, b.y);
+}
+__device__ void emit_remote_raw(const Dev &d, u64 guid, u32 slot, u32 xflags, u64 value, u64 tag) {
+    u32 loc = OCRGPU_GUID_LOCATION(guid);
+    if (d.send == nullptr || loc >= d.n_loc) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
     u32 pos = atomicAdd(&d.send_cnt[loc * 32], 1u);
     if (pos >= d.send_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
-    d.send[(size_t)loc * d.send_cap + pos] = SendRec{guid, slot, xflags, b.x, b.y};
+    d.send[(size_t)loc * d.send_cap + pos] = SendRec{guid, slot, xflags, value, tag};
 }
 
-
-struct Step { // per-launch constants, identical in every workgroup
-    u32 mode, r_begin, r_end, q_begin, q_end, r_base, q_base; u32 *cnt_r, *cnt_q;
-};
 
 // Fan `nseg` fired events out over the whole workgroup, edge-balanced: lane t takes edge t of the
 // concatenated rows (binary search of the LDS prefix sums), so a 10k-waiter row and 63 one-waiter
@@ -337,7 +427,7 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
             u64 w = d.waiters[seg[lo].row + (t - start)];
             u32 whi = (u32)(w >> 32);
             dst = (u32)w; flags = whi >> 28; slot = whi & 0x0FFFFFFFu; payload = seg[lo].payload;
-            if (flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, dst, slot, payload, flags); ++n_edt_sat; }
+            if (flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, S, dst, slot, payload, flags); ++n_edt_sat; }
             else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote(d, rd.guid, rd.slot, rd.flags, payload); }
             else {
                 to_evt = true; ++n_evt_sat;
@@ -558,14 +648,15 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             u32 kind = 0;
             if (act) {
                 r = d.q[i];
-                if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, r.dst, r.slot, r.payload, r.flags); ++n_edt_sat; }
+                if (r.flags & RF_LAZYWALK) lazy_walk(d, r.dst, r.slot);
+                else if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, S, r.dst, r.slot, r.payload, r.flags); ++n_edt_sat; }
                 else if (!(r.flags & RF_FIRED)) { kind = (*evt_state(d, r.dst) >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
             }
             u32 ri = S.r_base + wave_append(S.cnt_r, ready);
             if (ready) d.fired[ri] = r.dst;
             bool fire = latch_group(d, is_latch, r.dst, r.slot);
             if (act && (r.flags & RF_FIRED)) fire = true;
-            else if (act && !(r.flags & RF_DST_EDT) && !is_latch) {
+            else if (act && !(r.flags & (RF_DST_EDT | RF_LAZYWALK)) && !is_latch) {
                 if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM || kind == OCREVT_COUNTED) fire = evt_satisfy_simple(d, r.dst, kind, r.payload);
                 else atomicAdd(&c->err[(*evt_state(d, r.dst) & 0xFF) == ST_ABSENT ? ERR_BAD_OP : ERR_DEAD_EVENT], 1u);
             }
@@ -647,10 +738,10 @@ __global__ void k_event_create(Dev d, u64 n, const u32 *kind, const s32 *arg, u3
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 k = kind[i], x = first_idx + (u32)i;
-    u32 hi = 0;
-    if (k == OCREVT_COUNTED) { // nbDeps rides in bits 16..31 of the state word (hc-event.c:1600-1612: nbDeps > 0)
-        if (arg[i] <= 0 || arg[i] > 0xFFFF) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return; }
-        hi = (u32)arg[i] << 16;
+    const u32 hi = 0;
+    if (k == OCREVT_COUNTED) { // nbDeps > 0 (hc-event.c:1600-1612); the count lives in counted[x]
+        if (arg[i] <= 0) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return; }
+        d.counted[x] = (u64)(u32)arg[i] << 32;
     } else if (k < OCREVT_ONCE || k > OCREVT_LATCH) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return; } // CHANNEL: not on the engine
     d.evt[x] = EvtRec{0, 0, ST_LIVE | (k << 8) | hi, k == OCREVT_LATCH ? arg[i] : 0};
     u64 g = gin ? gin[i] : mkguid(d.location, evt_kind_to_guid_kind(k), first_counter + i);
@@ -736,15 +827,6 @@ __device__ bool resolve_dst(const Dev &d, u64 g, u32 slot, u32 &idx, u32 &flags,
     return slot < (1u << 28);
 }
 
-// registerWaiterEventHcCounted on a satisfied event (hc-event.c:1211-1238): the registration is counted, the last one
-// destroys the event
-__device__ __forceinline__ void counted_late_registration(const Dev &d, u32 x) {
-    u32 *sk = evt_state(d, x);
-    if (((*sk >> 8) & 0xFF) != OCREVT_COUNTED) return;
-    u32 o = atomicSub(sk, 1u << 16);
-    if ((o >> 16) == 1u) atomicExch(sk, (u32)ST_DESTROYED | (OCREVT_COUNTED << 8));
-}
-
 // ocrAddDependence classification (hc-policy.c:2857-3074)
 __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode, u32 nanny) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -764,8 +846,17 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
         if (!sv) { atomicAdd(&d.ctrl->err[is_event_kind(sk) ? ERR_LATE_WAITER : ERR_BAD_OP], 1u); return; }
         if (sk == OCRGPU_KIND_DB) { emit_remote(d, dg, slot[i], xf, (u32)sv); return; }
         if (!is_event_kind(sk)) { bad_op(d); return; }
-        u32 x = (u32)(sv - 1), st = *evt_state(d, x) & 0xFF;
-        if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); counted_late_registration(d, x); emit_remote(d, dg, slot[i], xf, pv); return; }
+        u32 x = (u32)(sv - 1);
+        const u32 sw = *evt_state(d, x);
+        u32 st = sw & 0xFF;
+        bool lazy = false;
+        if (r_edt && slot[i] > 0 && ((sw >> 8) & 0xFF) == OCREVT_COUNTED && (st == ST_SAT || st == ST_LIVE)) {
+            // the EDT's frontier is known where the EDT lives: hold the COUNT back and let its owner say when
+            lazy = true;
+            atomicAdd((unsigned long long *)&d.counted[x], 1ull);
+            emit_remote_raw(d, dg, slot[i], XF_LAZYREG, s, 0ull);
+        }
+        if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); if (!lazy) counted_late_registration(d, x); emit_remote(d, dg, slot[i], xf, pv); return; }
         if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }
         u32 ri = atomicAdd(&d.ctrl->rdst_tail, 1u), li = atomicAdd(&d.ctrl->log_tail, 1u);
         if (ri >= d.rdst_cap || li >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
@@ -784,8 +875,25 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
     if (sk == OCRGPU_KIND_DB) { q_push(d, Rec{didx, (u32)sv, dslot, dflag | mnull}); return; } // mode recorded, then satisfy
     if (!is_event_kind(sk)) { bad_op(d); return; }
     u32 x = (u32)(sv - 1);
-    u32 st = *evt_state(d, x) & 0xFF;
-    if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); counted_late_registration(d, x); q_push(d, Rec{didx, pv, dslot, dflag | mnull}); return; } // registerWaiterEventHcPersist :1143-1155
+    const u32 sw = *evt_state(d, x);
+    u32 st = sw & 0xFF;
+    bool lazy = false;
+    if (d_edt && slot[i] > 0 && ((sw >> 8) & 0xFF) == OCREVT_COUNTED && (st == ST_SAT || st == ST_LIVE)) {
+        // COUNTED source on a pre-slot the EDT's frontier has not reached (an earlier pre-slot is not satisfied yet):
+        // the data path registers now, the COUNT waits for the frontier (registerSignalerTaskHc hc-task.c:1391-1405)
+        EdtLine *L = &d.edt[didx];
+        const u32 *sl = (dflag & RF_INLINE) ? L->slot : d.slots + L->slot[0];
+        u32 f = 0;
+        while (f < slot[i] && (sl[f] & SLOT_MARK)) ++f;
+        if (f < slot[i]) {
+            lazy = true;
+            atomicOr(&L->pending, PEND_LAZY);
+            lazy_insert(d, lazy_key(didx, LAZY_FRONT), f);
+            lazy_insert(d, lazy_key(didx, slot[i]), x);
+            atomicAdd((unsigned long long *)&d.counted[x], 1ull);
+        }
+    }
+    if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); if (!lazy) counted_late_registration(d, x); q_push(d, Rec{didx, pv, dslot, dflag | mnull}); return; } // registerWaiterEventHcPersist :1143-1155
     if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }    // registerWaiterEventHc :1078-1083
     // Payload pre-resolution: when what this dependence will deliver is already known -- nothing (DB_MODE_NULL),
     // or the output DB / NULL_GUID of a built-in HASH / NOP body behind an output event -- write the pre-slot word
@@ -911,8 +1019,27 @@ __device__ void apply_record(const Dev &d, const SendRec &r, u32 proxy) {
         if ((old & 0xFF) != ST_LIVE && (old & 0xFF) != ST_SAT) atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
         return;
     }
+    if (r.flags & XF_ACTIVATE) {
+        u64 v = (OCRGPU_GUID_LOCATION(r.guid) == d.location && OCRGPU_GUID_KIND(r.guid) == OCRGPU_KIND_EVT_COUNTED) ? gtab_get(d, r.guid) : 0;
+        if (!v) { bad_op(d); return; }
+        counted_activate(d, (u32)(v - 1));
+        return;
+    }
     u32 didx, dslot, dflag;
     if (OCRGPU_GUID_LOCATION(r.guid) != d.location || !resolve_dst(d, r.guid, r.slot, didx, dflag, dslot)) { bad_op(d); return; }
+    if (r.flags & XF_LAZYREG) { // same decision as k_add_dep makes for a local COUNTED source
+        if (!(dflag & RF_DST_EDT)) { bad_op(d); return; }
+        EdtLine *L = &d.edt[didx];
+        const u32 *sl = (dflag & RF_INLINE) ? L->slot : d.slots + L->slot[0];
+        u32 f = 0;
+        while (f < r.slot && (sl[f] & SLOT_MARK)) ++f;
+        if (f < r.slot) {
+            atomicOr(&L->pending, PEND_LAZY);
+            lazy_insert(d, lazy_key(didx, LAZY_FRONT), f);
+            lazy_insert(d, lazy_key(didx, r.slot), r.value);
+        } else emit_remote_raw(d, r.value, 0u, XF_ACTIVATE, 0ull, 0ull);
+        return;
+    }
     u32 pay = 0;
     if (r.flags & XF_HAS_DB) { d.db[proxy] = make_ulonglong2(r.value, r.tag); pay = proxy + 1; }
     if ((dflag & RF_DST_EDT) && (r.flags & XF_MODE_NULL)) dflag |= RF_MODE_NULL;
@@ -1076,13 +1203,17 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); return OCRGPU_EHIP; } } while (0)
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
-struct Snapshot { EdtLine *edt; EvtRec *evt; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries; bool valid; };
+struct Snapshot { EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries; bool valid; };
+static void snap_free(Snapshot &s) {
+    (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.counted); (void)hipFree(s.lazy_tab); (void)hipFree(s.slots); (void)hipFree(s.fired); (void)hipFree(s.ctrl);
+    s.valid = false;
+}
 
 struct ocrgpu_engine {
     int device; hipStream_t stream; ocrgpu_config_t cfg; Dev d;
     std::vector<void *> allocs;
     // host mirrors
-    u32 n_edt, n_evt, n_db; u64 n_slots, n_script, script_cap; u64 counter; u64 edges_upper;
+    u32 n_edt, n_evt, n_db; u64 n_slots, n_script, script_cap, lazy_cap; u64 counter; u64 edges_upper;
     bool csr_dirty; u32 q_cap;
     // staging
     char *stage_dev; size_t stage_dev_cap, stage_dev_off; char *stage_host; size_t stage_host_cap;
@@ -1212,6 +1343,14 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.edt_script_len, 4 * (size_t)cfg->max_edt));
     TRY(dalloc(e, (void **)&d.slots, 4 * (size_t)d.max_slots));
     TRY(dalloc(e, (void **)&d.evt, sizeof(EvtRec) * (size_t)cfg->max_evt));
+    TRY(dalloc(e, (void **)&d.counted, 8 * (size_t)cfg->max_evt));
+    { // held-back COUNTED registrations: 2 entries each at most; OCRGPU_MAX_LAZY overrides the default bound
+        u64 want = getenv("OCRGPU_MAX_LAZY") ? (u64)atoll(getenv("OCRGPU_MAX_LAZY")) : 4 * (u64)cfg->max_evt + 1024;
+        if (want > (1ull << 22) && !getenv("OCRGPU_MAX_LAZY")) want = 1ull << 22;
+        u64 lc = 4096; while (lc < 4 * want) lc <<= 1;
+        d.lazy_mask = lc - 1; e->lazy_cap = lc;
+        TRY(dalloc(e, (void **)&d.lazy_tab, 16 * (size_t)lc));
+    }
     TRY(dalloc(e, (void **)&d.waiters, 8 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.log_src, 4 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.log_rec, 8 * (size_t)d.max_edges));
@@ -1270,7 +1409,7 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stage_dev) (void)hipFree(e->stage_dev);
     if (e->scan_partials) (void)hipFree(e->scan_partials);
-    if (e->snap.valid) { (void)hipFree(e->snap.edt); (void)hipFree(e->snap.evt); (void)hipFree(e->snap.fired); (void)hipFree(e->snap.ctrl); }
+    if (e->snap.valid) snap_free(e->snap);
     if (e->pinned_done) (void)hipHostFree(e->pinned_done);
     if (e->have_events) { (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1); }
     delete e;
@@ -1691,9 +1830,13 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     ENTER(e);
     int r = seal(e); if (r) return r;
     Dev &d = e->d; Snapshot &s = e->snap;
-    if (s.valid) { HIPCHK(hipStreamSynchronize(e->stream)); (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.fired); (void)hipFree(s.ctrl); s.valid = false; }
+    if (s.valid) { HIPCHK(hipStreamSynchronize(e->stream)); snap_free(s); }
     HIPCHK(hipMalloc((void **)&s.edt, sizeof(EdtLine) * (size_t)e->n_edt + 64));
     HIPCHK(hipMalloc((void **)&s.evt, sizeof(EvtRec) * (size_t)e->n_evt + 64));
+    HIPCHK(hipMalloc((void **)&s.counted, 8 * (size_t)e->n_evt + 64));
+    HIPCHK(hipMalloc((void **)&s.lazy_tab, 16 * (size_t)e->lazy_cap));
+    s.n_slots = e->n_slots;
+    HIPCHK(hipMalloc((void **)&s.slots, 4 * (size_t)s.n_slots + 64));
     HIPCHK(hipMemcpyAsync(e->pinned_done + 33012, &d.ctrl->r_tail, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     s.n_fired_entries = e->pinned_done[33012];
@@ -1702,6 +1845,9 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt; s.n_db = e->n_db; e->snap_pop_cursor = e->pop_cursor;
     HIPCHK(hipMemcpyAsync(s.edt, d.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(s.evt, d.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
+    if (e->n_evt) HIPCHK(hipMemcpyAsync(s.counted, d.counted, 8 * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(s.lazy_tab, d.lazy_tab, 16 * (size_t)e->lazy_cap, hipMemcpyDeviceToDevice, e->stream));
+    if (s.n_slots) HIPCHK(hipMemcpyAsync(s.slots, d.slots, 4 * (size_t)s.n_slots, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(s.fired, d.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(s.ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
     return 0;
@@ -1716,9 +1862,12 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     if (e->d.send_cnt) k_exchange_reset<<<1, 1024, 0, e->stream>>>(e->d);
     HIPCHK(hipMemcpyAsync(d.edt, s.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.evt, s.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
+    if (e->n_evt) HIPCHK(hipMemcpyAsync(d.counted, s.counted, 8 * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d.lazy_tab, s.lazy_tab, 16 * (size_t)e->lazy_cap, hipMemcpyDeviceToDevice, e->stream));
+    // pre-slot words carry the "satisfied" marks: overflow words go back to what they were (inline ones are in the lines)
+    if (s.n_slots) HIPCHK(hipMemcpyAsync(d.slots, s.slots, 4 * (size_t)s.n_slots, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(d.fired, s.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.ctrl, s.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
-    if (e->cfg.flags & OCRGPU_F_NANNY) HIPCHK(hipMemsetAsync(d.slots, 0, 4 * (size_t)e->n_slots, e->stream));
     HIPCHK(hipMemsetAsync(d.blk_stats, 0, 8 * 4 * MAX_GRID, e->stream)); // statistics restart with the re-armed DAG
     return 0;
 }

@@ -1,7 +1,6 @@
-"""Fuzz parity on the GPU: random well-formed OCR programs (streams.random_stream, eager_safe flavour -- see its
-docstring and DESIGN.md s3 for the one documented difference the other flavour would show) resolved by the HIP
-engine must give the result record of the CPU restatement, and the digest the reference runtime produced for the
-committed seeds (tests/golden/fuzz.json); also split over 2 and 3 GUID partitions."""
+"""Fuzz parity on the GPU: random well-formed OCR programs (streams.random_stream, both flavours) resolved by the
+HIP engine must give the result record of the CPU restatement, and the digest the reference runtime produced for
+the committed seeds (tests/golden/fuzz.json); also split over 2 and 3 GUID partitions."""
 import json
 import os
 
@@ -15,12 +14,13 @@ from oracle import ref as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("safe", [True, False])
 @pytest.mark.parametrize("nanny", [True, False])
-def test_engine_matches_reference_digests_and_restatement(nanny, golden_dir):
+def test_engine_matches_reference_digests_and_restatement(nanny, safe, golden_dir):
     with open(os.path.join(golden_dir, "fuzz.json")) as f:
         fuzz = json.load(f)
     for seed in range(200):
-        s = streams.random_stream(seed, n=36 if seed < streams.FUZZ_SEEDS else 64, eager_safe=True)
+        s = streams.random_stream(seed, n=36 if seed < streams.FUZZ_SEEDS else 64, eager_safe=safe)
         r, st = engine.run_stream(s, flags=engine.F_NANNY if nanny else 0)
         assert sum(st.err) == 0, f"{s.name}: device flagged errors {list(st.err)}"
         assert r.diff(O.run_restatement(s)) == [], s.name
@@ -30,8 +30,8 @@ def test_engine_matches_reference_digests_and_restatement(nanny, golden_dir):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_fuzz_programs_are_partition_invariant(world):
-    for seed in range(40):
-        s = streams.random_stream(seed, n=48, eager_safe=True)
+    for seed in range(60):
+        s = streams.random_stream(seed, n=48, eager_safe=bool(seed & 1))
         parts = D.build_lockstep([D.Partition(s, r, world) for r in range(world)])
         D.resolve_lockstep(parts)
         res = D.gather_result_lockstep(s, parts)
@@ -85,3 +85,27 @@ def test_latch_delta_through_the_api():
     lv, _ = eng.read_edts(0, 3)
     assert list(lv >= 0) == [True, True, False]
     eng.close()
+
+
+def test_lazy_frontier_counted_event():
+    """COUNTED event on pre-slot 1 of an EDT whose pre-slot 0 is never satisfied: the registration is never made, the
+    event keeps its count (hc-task.c:1286-1338); a second EDT whose frontier does get there uses it up."""
+    from ocr_amd.opstream import BODY_NOP, EVT_COUNTED, EVT_ONCE, EVS_DESTROYED, EVS_LIVE_SAT, MODE_RO, Builder
+    b = Builder("lazy_frontier_gpu")
+    start = b.evt(EVT_ONCE)
+    never = b.evt(EVT_ONCE)
+    kept, used = b.evt(EVT_COUNTED, 1), b.evt(EVT_COUNTED, 1)
+    stuck = b.edt(2, BODY_NOP)
+    b.add_dep(never, stuck, 0, MODE_RO)
+    b.add_dep(kept, stuck, 1, MODE_RO)
+    runs = b.edt(2, BODY_NOP)
+    b.add_dep(used, runs, 1, MODE_RO)          # registered before pre-slot 0 has its dependence: held back
+    b.add_dep(start, runs, 0, MODE_RO)
+    b.satisfy(kept, 0)
+    b.satisfy(used, 0)
+    s = b.finish([runs], start)
+    ref = O.run_restatement(s)
+    assert ref.evt_state[2] & 0xFF == EVS_LIVE_SAT and ref.evt_state[3] & 0xFF == EVS_DESTROYED
+    for flags in (engine.F_NANNY, 0):
+        r, st = engine.run_stream(s, flags=flags)
+        assert sum(st.err) == 0 and r.diff(ref) == []
