@@ -161,6 +161,8 @@ static void op_add_dep(eng_t *E, const ocrops_op_t *op) {
     int dst_is_evt = (dc == OCRREF_EVT || dc == OCRREF_OUTEVT);
     uint32_t dst = dst_is_evt ? ev_index(E, op->b) : (uint32_t)OCRREF_IDX(op->b);
     uint8_t mode_null = (!dst_is_evt && op->mode == OCRMODE_NULL);
+    /* a pre-slot the EDT does not have: ASSERT(slot < depc) in the reference (hc-task.c:1229,1374), a malformed op here */
+    if (!dst_is_evt && (dc != OCRREF_EDT || dst >= E->h->n_edt || op->slot >= E->edt[dst].depc)) { E->err[ERR_BAD_OP]++; return; }
     if (sc == OCRREF_NULL || sc == OCRREF_DB || sc == OCRREF_OUTDB) {
         /* convertDepAddToSatisfy hc-policy.c:2857-2902; DB->EDT records the mode first */
         uint8_t mn = (sc == OCRREF_NULL) ? 0 : mode_null; /* NULL src: mode not recorded (signalers[].mode stays -1) */

@@ -30,12 +30,18 @@ def make(spec):
     raise SystemExit(f"unknown workload {spec}")
 
 
+def stage(msg):
+    """one line per finished stage, so a long run shows where it is (and a hung stage shows as silence)"""
+    print(f"[bench_configs {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def run(spec, steps=3, warmup=1, parity=True):
     from ocr_amd import engine, opstream
     from ocr_amd import opstream as ops
     t0 = time.time()
     s = make(spec)
     gen_s = time.time() - t0
+    stage(f"{spec}: generated {s.n_edt} EDTs, {len(s.main)} main ops in {gen_s:.1f} s")
     assert int(s.main["op"][-1]) == ops.OP_SATISFY, "generators end with the start satisfy"
     start_op = s.main[-1:]
     built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
@@ -45,6 +51,7 @@ def run(spec, steps=3, warmup=1, parity=True):
     eng.snapshot()
     eng.sync()
     build_s = time.time() - t0
+    stage(f"{spec}: built on the engine in {build_s:.1f} s")
     start_guid = prog._guids(start_op["a"])
     start_db = prog._guids(start_op["b"])
 
@@ -70,6 +77,7 @@ def run(spec, steps=3, warmup=1, parity=True):
 
     for _ in range(warmup):
         st = step()
+    stage(f"{spec}: warm-up done ({int(st.fired)} EDTs fired, {int(st.levels)} levels)")
     k0, l0 = eng.stats().step_kernel_ns, eng.stats().launches
     eng.sync()
     t0 = time.perf_counter()
@@ -89,6 +97,7 @@ def run(spec, steps=3, warmup=1, parity=True):
            "ms_per_resolve": dt * 1e3, "ms_breakdown_synced": {k: round(v / steps * 1e3, 3) for k, v in tm.items()}, "ms_k_step": kern * 1e3, "launches": launches,
            "sat_per_s": int(s.meta.get("n_satisfactions", n_sat)) / dt, "edts_per_s": int(st.fired) / dt,
            "gen_s": round(gen_s, 2), "build_s": round(build_s, 2)}
+    stage(f"{spec}: timed {steps} steps, {dt * 1e3:.2f} ms per resolve")
     if parity:
         from oracle import ref as O            # checker only
         t0 = time.time()
