@@ -137,7 +137,7 @@ def test_capacity_errors_are_reported_not_faulted():
     eng = engine.Engine(max_edt=4, max_evt=2, max_db=2)
     with pytest.raises(engine.OcrGpuError) as ei:
         eng.edt_create([1] * 5, [BODY_NOP] * 5, list(range(5)))
-    assert ei.value.args[0] == -12                  # OCRGPU_ENOMEM
+    assert ei.value.code == -12                     # OCRGPU_ENOMEM
     with pytest.raises(engine.OcrGpuError):
         eng.event_create([EVT_ONCE] * 3)
     with pytest.raises(engine.OcrGpuError):
