@@ -497,8 +497,10 @@ __device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, 
 }
 
 #ifdef OCRGPU_STAMPS
+#define STAMP_LAUNCHES 8u // consecutive launches K0 .. K0+7 keep a per-workgroup table each
+#define STAMP_AT(j) d.dbg[16 + (size_t)(K - (u32)d.dbg[15]) * 8 * MAX_GRID + 8 * blockIdx.x + (j)]
 #define STAMP(k) do { if (threadIdx.x == 0) { u64 _t = __builtin_amdgcn_s_memrealtime(); if (blockIdx.x == 0) { d.dbg[k] += _t - _t0; _t0 = _t; } \
-                                              if (K == (u32)d.dbg[15]) d.dbg[16 + 8 * blockIdx.x + 2 + (k)] = _t; } } while (0)
+                                              if (K - (u32)d.dbg[15] < STAMP_LAUNCHES) STAMP_AT(2 + (k)) = _t; } } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #endif
@@ -508,7 +510,8 @@ template <bool NANNY>
 __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #ifdef OCRGPU_STAMPS
     u64 _t0 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && K == (u32)d.dbg[15]) d.dbg[16 + 8 * blockIdx.x] = _t0; // per-workgroup entry time of ONE chosen launch
+    if (threadIdx.x == 0 && K - (u32)d.dbg[15] < STAMP_LAUNCHES) // entry time; the XCD this workgroup runs on in the top 4 bits
+        STAMP_AT(0) = _t0 | ((u64)(__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20) & 0xFu) << 60);
 #endif
     __shared__ Seg seg[BLK];
     __shared__ u32 wave_sums[4];
@@ -553,6 +556,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     u32 per = (count + d.spread_wgs - 1) / d.spread_wgs;
     if (per < 1) per = 1;
     if (per > BLK) per = BLK;
+    if (per >= 16u) per = (per + 15u) & ~15u; // whole 16-entry (64-B) chunks, see the FIRE loop
     u32 part = (count + per - 1) / per; if (part > gridDim.x) part = gridDim.x; // 0 for a forced empty level
     if (blockIdx.x >= part) return; // workgroups beyond the work leave at once
     STAMP(0);
@@ -560,9 +564,24 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     const bool body_first = d.n_loc > 1;
     if (S.mode == MODE_FIRE) {
         // ---- taskExecute + taskEpilogue for one level (hc-task.c:1864-2181, 1707-1862) ----
-        for (u32 cb = S.r_begin + blockIdx.x * per; cb < S.r_end; cb += gridDim.x * per) {
+        // The ready log is sparse and its valid entries are not spread evenly: an EDT is made ready by the LAST of its
+        // edges, and late edges are appended late, so the holes sit at the front of a level's range and the EDTs at
+        // its end.  Each workgroup therefore takes its entries as 16-entry chunks dealt round-robin over the whole
+        // range (chunk c of workgroup b = chunk c*W + b of the pass), not as one contiguous run.
+        // Only when there are few workgroups per CU: a wide level has many more workgroups than CUs, which evens the load
+        // out by itself, and keeps its contiguous (better coalesced) runs.
+        const u32 CH = (per >= 16u && part <= 512u) ? 16u : per;
+        const u32 pass_len = gridDim.x * per;
+        for (u32 pb = S.r_begin; pb < S.r_end; pb += pass_len) {
+            const u32 left = S.r_end - pb;
+            const u32 W = left >= pass_len ? gridDim.x : (left + per - 1) / per; // workgroups working in this pass
+            if (blockIdx.x >= W) break;
             u32 deg = 0; Seg sg = {0, 0, 0};
-            const u32 i = threadIdx.x < per ? cb + threadIdx.x : S.r_end;
+            u32 i = S.r_end;
+            if (threadIdx.x < per) {
+                const u32 ii = pb + ((threadIdx.x / CH) * W + blockIdx.x) * CH + threadIdx.x % CH;
+                if (ii < S.r_end) i = ii;
+            }
             // Critical path per level: ready-log entry -> the EDT's 64-B line -> waiter row -> atomicSub -> log store.
             // The body's gathers (the DBs named by the pre-slot words, which sit in the same line) are issued
             // BEFORE the fan-out and consumed after it, so they ride under it.
@@ -692,7 +711,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     }
     STAMP(5);
 #ifdef OCRGPU_STAMPS
-    if (threadIdx.x == 0 && K == (u32)d.dbg[15]) d.dbg[17 + 8 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && K - (u32)d.dbg[15] < STAMP_LAUNCHES) STAMP_AT(1) = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -1361,7 +1380,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.level_start, 4 * ((size_t)d.max_levels + 2)));
     TRY(dalloc(e, (void **)&d.q, sizeof(Rec) * (size_t)q_cap, false));
     TRY(dalloc(e, (void **)&d.blk_stats, 8 * 4 * MAX_GRID));
-    TRY(dalloc(e, (void **)&d.dbg, 8 * (16 + 8 * MAX_GRID)));
+    TRY(dalloc(e, (void **)&d.dbg, 8 * (16 + 8 * 8 * MAX_GRID)));
     { u64 k = getenv("OCRGPU_STAMP_K") ? (u64)atoll(getenv("OCRGPU_STAMP_K")) : 0; (void)hipMemcpyAsync(&d.dbg[15], &k, 8, hipMemcpyHostToDevice, e->stream); (void)hipStreamSynchronize(e->stream); }
     e->script_cap = (u64)cfg->max_edt + 1024;
     TRY(dalloc(e, (void **)&d.scripts, sizeof(Script) * e->script_cap));
@@ -1389,9 +1408,16 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     { u64 h[16]; if (e->d.dbg && hipMemcpy(h, e->d.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
         fprintf(stderr, "[stamps, 10ns ticks of workgroup 0 summed over %llu launches] entry %llu | A(loads) %llu | scan %llu | fanout %llu | body %llu | ticket %llu\n",
                 (unsigned long long)e->launches_total, (unsigned long long)h[0], (unsigned long long)h[1], (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)h[4], (unsigned long long)h[5]);
+        if (getenv("OCRGPU_STAMP_DUMP")) { // raw tables of the 8 stamped launches, for tools/stamp_tail.py
+            std::vector<u64> all(16 + 8 * 8 * MAX_GRID);
+            if (hipMemcpy(all.data(), e->d.dbg, 8 * all.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+                FILE *f = fopen(getenv("OCRGPU_STAMP_DUMP"), "wb"); if (f) { fwrite(all.data(), 8, all.size(), f); fclose(f); }
+            }
+        }
         std::vector<u64> hb(16 + 8 * MAX_GRID);
         if (hipMemcpy(hb.data(), e->d.dbg, 8 * hb.size(), hipMemcpyDeviceToHost) == hipSuccess) {
             u64 t0 = ~0ull; int n = 0;
+            for (int b = 0; b < MAX_GRID; ++b) hb[16 + 8 * b] &= (1ull << 60) - 1; // strip the XCD id
             for (int b = 0; b < MAX_GRID; ++b) { u64 st = hb[16 + 8 * b]; if (st && hb[17 + 8 * b] && st < t0) t0 = st; }
             // per phase: min / median / max over the working workgroups, 10ns ticks after the first entry
             static const char *nm[8] = {"entry", "exit", "decided", "lines", "scan", "fanout", "loopend", "stats"};
