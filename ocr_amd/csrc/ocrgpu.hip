@@ -43,6 +43,7 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_
 #define RF_PREFILLED 8u // EDT destination: the payload was already written at registration (static payload)
 #define RF_FIRED 16u    // record only: the event already fired (its satisfy logic ran inline), just fan out
 #define RF_PIECE 32u    // record only: fan out piece `slot` (BIG_ROW edges) of the fired event's row
+#define RF_CHANGEN 128u // record only (with RF_FIRED): a CHANNEL pairing; `slot` = index in waiters[] of the waiter that takes `payload`
 #define RF_LAZYWALK 64u // record only: pre-slot `slot` of frontier-tracked EDT `dst` was satisfied -> lazy_walk()
 #define INLINE_SLOTS 6u
 #define SLOT_MARK 0x80000000u  // pre-slot word: the slot has been satisfied
@@ -69,6 +70,10 @@ struct alignas(64) EdtLine {
 };
 static_assert(sizeof(EdtLine) == 64, "EdtLine must be one 64-byte sector");
 struct Rec { u32 dst, payload, slot, flags; };      // one pending satisfy: dst = event idx | EDT idx
+// CHANNEL event (hc-event.c:2081-2156): generation k pairs the k-th satisfy with the k-th registered waiter.  Two rings of
+// `cap` (= maxGen) entries: waiters in the top end of waiters[] (so a pairing is fanned out like a 1-edge row), payloads
+// in chan_sat[].  counted[x] = [satisfies so far:32 | registrations so far:32], one atomic per op.
+struct ChanRec { u32 cap, wait_base, sat_base, pad; };
 struct Script { u32 target, payload, slot, op_kind; }; // op | payload_kind<<8
 // A satisfy whose destination lives on another partition (GPU): what crosses xGMI instead of the reference's
 // marshalled ocrPolicyMsg_t (hc-dist-policy.c:2208, mpi-comm-platform.c:1055).  The datablock travels by value
@@ -96,7 +101,7 @@ struct alignas(128) Ctrl {
     u32 level, r_end, q_begin, pad0, n_levels, pad1[27];
     u32 r_tail; u32 pad2[31];   // atomics (own cache lines)
     u32 q_tail; u32 pad3[31];
-    u32 log_tail; u32 rdst_tail; u32 pad4[30];
+    u32 log_tail; u32 rdst_tail; u32 chan_count, chan_wait_used, chan_sat_used; u32 pad4[27];
     u32 err[8]; u32 pad5[24];
     // during a run
     State state[2];
@@ -111,7 +116,9 @@ struct Dev {
     u32 *slots;                 // overflow pre-slot words (depc > 6): dbidx+1 (0 = NULL_GUID); bit31 = satisfied (nanny)
     // events: explicit [0,max_evt) in `evt`; the output event of EDT e is event max_evt+e and lives in edt[e]
     EvtRec *evt;
-    u64 *counted;               // COUNTED events: the accounting word (CNT_SAT | left << 32 | lazy pending), see counted_*()
+    u64 *counted;               // COUNTED events: the accounting word (CNT_SAT | left << 32 | lazy pending), see counted_*();
+                                // CHANNEL events: satisfies so far << 32 | registrations so far
+    ChanRec *chan; u32 *chan_sat; u32 chan_sat_cap; // CHANNEL events: evt[x].val = index into chan[]
     ulonglong2 *lazy_tab; u64 lazy_mask; // (EDT, pre-slot) -> COUNTED event waiting for the frontier; (EDT, LAZY_FRONT) -> frontier
     u64 *waiters;               // CSR payload: lo = dst ; hi = flags<<28 | (pre-slot k of the EDT | latch slot)
     u32 *log_src; u64 *log_rec; // registration log the CSR is built from
@@ -335,6 +342,18 @@ __device__ __forceinline__ bool evt_satisfy_simple(const Dev &d, u32 x, u32 kind
     return false;
 }
 
+// satisfyEventHcChannel (hc-event.c:2125-2156): generation k of the channel.  True when waiter k is already in line
+// (wpos = where it sits in waiters[]); else the payload queues for the waiter to come.
+__device__ __forceinline__ bool chan_satisfy(const Dev &d, u32 x, u32 payload, u32 &wpos) {
+    const ChanRec c = d.chan[(u32)*evt_val(d, x)];
+    const u64 old = atomicAdd((unsigned long long *)&d.counted[x], 1ull << 32);
+    const u32 k = (u32)(old >> 32), nw = (u32)old;
+    if (k < nw) { wpos = c.wait_base + k % c.cap; return true; }
+    if (k - nw >= c.cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return false; } // more than maxGen satisfies queued (ASSERT :2023)
+    d.chan_sat[c.sat_base + k % c.cap] = payload;
+    return false;
+}
+
 // satisfyEventHcLatch (hc-event.c:812-868) for every latch record held by this wave: lanes that hit the
 // same latch are grouped (readfirstlane + ballot) and ONE atomic applies their summed +1/-1; the group
 // fires iff the counter it leaves is 0 (well-formed programs never pass through 0 before their last op).
@@ -441,14 +460,16 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         // recursing into processMessage, hc-event.c:335-367); only an event that FIRES costs a queue record
         if (__ballot(to_evt)) {
             bool fire = latch_group(d, is_latch, dst, slot);
+            u32 cw = 0; bool paired = false;
             if (to_evt && !is_latch) {
                 if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM || kind == OCREVT_COUNTED) fire = evt_satisfy_simple(d, dst, kind, payload);
+                else if (kind == OCREVT_CHANNEL && (*evt_state(d, dst) & 0xFF) == ST_LIVE) paired = chan_satisfy(d, dst, payload, cw);
                 else atomicAdd(&c->err[ERR_DEAD_EVENT], 1u);
             }
-            bool toq = fire && *evt_deg(d, dst) != 0;
+            bool toq = (fire && *evt_deg(d, dst) != 0) || paired;
             u32 qi = S.q_base + wave_append(S.cnt_q, toq);
             if (toq) {
-                if (qi < d.q_cap) d.q[qi] = Rec{dst, payload, 0u, RF_FIRED};
+                if (qi < d.q_cap) d.q[qi] = paired ? Rec{dst, payload, cw, RF_FIRED | RF_CHANGEN} : Rec{dst, payload, 0u, RF_FIRED};
                 else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
             }
         }
@@ -674,9 +695,13 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             u32 ri = S.r_base + wave_append(S.cnt_r, ready);
             if (ready) d.fired[ri] = r.dst;
             bool fire = latch_group(d, is_latch, r.dst, r.slot);
-            if (act && (r.flags & RF_FIRED)) fire = true;
+            if (act && (r.flags & RF_CHANGEN)) { deg = 1; sg.row = r.slot; sg.payload = r.payload; } // a CHANNEL pairing made in a fan-out
+            else if (act && (r.flags & RF_FIRED)) fire = true;
             else if (act && !(r.flags & (RF_DST_EDT | RF_LAZYWALK)) && !is_latch) {
                 if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM || kind == OCREVT_COUNTED) fire = evt_satisfy_simple(d, r.dst, kind, r.payload);
+                else if (kind == OCREVT_CHANNEL && (*evt_state(d, r.dst) & 0xFF) == ST_LIVE) {
+                    u32 wp; if (chan_satisfy(d, r.dst, r.payload, wp)) { deg = 1; sg.row = wp; sg.payload = r.payload; } // the waiter in line takes it now
+                }
                 else atomicAdd(&c->err[(*evt_state(d, r.dst) & 0xFF) == ST_ABSENT ? ERR_BAD_OP : ERR_DEAD_EVENT], 1u);
             }
             if (fire) {
@@ -757,12 +782,21 @@ __global__ void k_event_create(Dev d, u64 n, const u32 *kind, const s32 *arg, u3
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 k = kind[i], x = first_idx + (u32)i;
-    const u32 hi = 0;
+    const u32 hi = 0; s32 arg_val = 0;
     if (k == OCREVT_COUNTED) { // nbDeps > 0 (hc-event.c:1600-1612); the count lives in counted[x]
         if (arg[i] <= 0) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return; }
         d.counted[x] = (u64)(u32)arg[i] << 32;
-    } else if (k < OCREVT_ONCE || k > OCREVT_LATCH) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return; } // CHANNEL: not on the engine
-    d.evt[x] = EvtRec{0, 0, ST_LIVE | (k << 8) | hi, k == OCREVT_LATCH ? arg[i] : 0};
+    } else if (k == OCREVT_CHANNEL) { // arg = maxGen (ring capacity); EVENT_CHANNEL_UNBOUNDED (<= 0) gets 1024 generations in flight
+        const u32 cap = arg[i] > 0 ? (u32)arg[i] : 1024u;
+        const u32 ord = atomicAdd(&d.ctrl->chan_count, 1u), wb = atomicAdd(&d.ctrl->chan_wait_used, cap), sb = atomicAdd(&d.ctrl->chan_sat_used, cap);
+        if (ord >= d.max_evt || (u64)sb + cap > d.chan_sat_cap || (u64)wb + cap + d.ctrl->log_tail > d.max_edges) {
+            atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return;
+        }
+        d.chan[ord] = ChanRec{cap, (u32)(d.max_edges - wb - cap), sb, 0u};
+        d.counted[x] = 0;
+        arg_val = (s32)ord;
+    } else if (k < OCREVT_ONCE || k > OCREVT_CHANNEL) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return; }
+    d.evt[x] = EvtRec{0, 0, ST_LIVE | (k << 8) | hi, k == OCREVT_LATCH ? arg[i] : arg_val};
     u64 g = gin ? gin[i] : mkguid(d.location, evt_kind_to_guid_kind(k), first_counter + i);
     if (gin && !given_ok(d, g, evt_kind_to_guid_kind(k))) return;
     gtab_put(d, g, (u64)x + 1);
@@ -846,6 +880,18 @@ __device__ bool resolve_dst(const Dev &d, u64 g, u32 slot, u32 &idx, u32 &flags,
     return slot < (1u << 28);
 }
 
+// registerWaiterEventHcChannel (hc-event.c:2081-2123): registration k of the channel.  True when satisfy k is already
+// queued (payload = what it carried: the caller delivers it at once); else the waiter record waits in line.
+__device__ __forceinline__ bool chan_register(const Dev &d, u32 x, u64 waiter, u32 &payload) {
+    const ChanRec c = d.chan[(u32)*evt_val(d, x)];
+    const u64 old = atomicAdd((unsigned long long *)&d.counted[x], 1ull);
+    const u32 k = (u32)old, ns = (u32)(old >> 32);
+    if (k < ns) { payload = d.chan_sat[c.sat_base + k % c.cap]; return true; }
+    if (k - ns >= c.cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return false; } // more than maxGen waiters in line (ASSERT :2005)
+    d.waiters[c.wait_base + k % c.cap] = waiter;
+    return false;
+}
+
 // ocrAddDependence classification (hc-policy.c:2857-3074)
 __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode, u32 nanny) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -877,8 +923,16 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
         }
         if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); if (!lazy) counted_late_registration(d, x); emit_remote(d, dg, slot[i], xf, pv); return; }
         if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }
+        if (((sw >> 8) & 0xFF) == OCREVT_CHANNEL) { // the waiter in line is a remote destination
+            u32 ri = atomicAdd(&d.ctrl->rdst_tail, 1u);
+            if (ri >= d.rdst_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+            d.rdst[ri] = RemoteDst{dg, slot[i], xf};
+            u32 pay;
+            if (chan_register(d, x, ((u64)(RF_REMOTE << 28) << 32) | (u64)ri, pay)) emit_remote(d, dg, slot[i], xf, pay);
+            return;
+        }
         u32 ri = atomicAdd(&d.ctrl->rdst_tail, 1u), li = atomicAdd(&d.ctrl->log_tail, 1u);
-        if (ri >= d.rdst_cap || li >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+        if (ri >= d.rdst_cap || (u64)li + d.ctrl->chan_wait_used >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
         d.rdst[ri] = RemoteDst{dg, slot[i], xf};
         d.log_src[li] = x;
         d.log_rec[li] = ((u64)(RF_REMOTE << 28) << 32) | (u64)ri;
@@ -914,6 +968,12 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
     }
     if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); if (!lazy) counted_late_registration(d, x); q_push(d, Rec{didx, pv, dslot, dflag | mnull}); return; } // registerWaiterEventHcPersist :1143-1155
     if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }    // registerWaiterEventHc :1078-1083
+    if (((sw >> 8) & 0xFF) == OCREVT_CHANNEL) {
+        const u32 dl = (!d_edt && OCRGPU_GUID_KIND(dst[i]) == OCRGPU_KIND_EVT_LATCH) ? RF_DST_LATCH : 0u;
+        u32 pay;
+        if (chan_register(d, x, ((u64)(((dflag | mnull | dl) << 28) | dslot) << 32) | (u64)didx, pay)) q_push(d, Rec{didx, pay, dslot, dflag | mnull});
+        return;
+    }
     // Payload pre-resolution: when what this dependence will deliver is already known -- nothing (DB_MODE_NULL),
     // or the output DB / NULL_GUID of a built-in HASH / NOP body behind an output event -- write the pre-slot word
     // now and let the satisfy be a bare counter decrement (no per-edge store on the hot path).
@@ -929,7 +989,7 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
         if (known) { pre = RF_PREFILLED; *((dflag & RF_INLINE) ? &d.edt[didx].slot[dslot] : &d.slots[(size_t)d.edt[didx].slot[0] + dslot]) = word; }
     }
     u32 li = atomicAdd(&d.ctrl->log_tail, 1u);
-    if (li >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+    if ((u64)li + d.ctrl->chan_wait_used >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // waiters[] top end = CHANNEL rings
     d.log_src[li] = x;
     u32 dlatch = (!d_edt && OCRGPU_GUID_KIND(dst[i]) == OCRGPU_KIND_EVT_LATCH) ? RF_DST_LATCH : 0u;
     d.log_rec[li] = ((u64)(((dflag | mnull | pre | dlatch) << 28) | dslot) << 32) | (u64)didx;
@@ -1203,6 +1263,10 @@ __global__ void k_read_events(Dev d, u32 first, u64 n, u64 *out) {
     if (st == ST_ABSENT) r = OCREVS(OCREVS_ABSENT, 0);
     else if (st == ST_DESTROYED) r = OCREVS(OCREVS_DESTROYED, 0);
     else if (st == ST_SAT) r = OCREVS(OCREVS_LIVE_SAT, m.val ? (u32)(db_gather(d, (u32)m.val).y + 1) : 0u);
+    else if (kind == OCREVT_CHANNEL) { // queued satisfies << 16 | waiters in line
+        const u64 a = d.counted[first + (u32)i]; const u32 ns = (u32)(a >> 32), nw = (u32)a;
+        r = OCREVS(OCREVS_LIVE_UNSAT, ((ns > nw ? ns - nw : 0u) << 16) | (nw > ns ? nw - ns : 0u));
+    }
     else r = OCREVS(OCREVS_LIVE_UNSAT, kind == OCREVT_LATCH ? (u32)m.val : 0u);
     out[i] = r;
 }
@@ -1222,9 +1286,9 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); return OCRGPU_EHIP; } } while (0)
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
-struct Snapshot { EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries; bool valid; };
+struct Snapshot { EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; u64 *chan_wait; u32 *chan_sat; u32 chan_wait_used, chan_sat_used; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries; bool valid; };
 static void snap_free(Snapshot &s) {
-    (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.counted); (void)hipFree(s.lazy_tab); (void)hipFree(s.slots); (void)hipFree(s.fired); (void)hipFree(s.ctrl);
+    (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.counted); (void)hipFree(s.lazy_tab); (void)hipFree(s.slots); (void)hipFree(s.chan_wait); (void)hipFree(s.chan_sat); (void)hipFree(s.fired); (void)hipFree(s.ctrl);
     s.valid = false;
 }
 
@@ -1363,6 +1427,9 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.slots, 4 * (size_t)d.max_slots));
     TRY(dalloc(e, (void **)&d.evt, sizeof(EvtRec) * (size_t)cfg->max_evt));
     TRY(dalloc(e, (void **)&d.counted, 8 * (size_t)cfg->max_evt));
+    TRY(dalloc(e, (void **)&d.chan, sizeof(ChanRec) * (size_t)cfg->max_evt));
+    d.chan_sat_cap = getenv("OCRGPU_CHAN_SLOTS") ? (u32)atoll(getenv("OCRGPU_CHAN_SLOTS")) : (u32)(d.max_edges < (1u << 22) ? d.max_edges : (1u << 22));
+    TRY(dalloc(e, (void **)&d.chan_sat, 4 * (size_t)d.chan_sat_cap));
     { // held-back COUNTED registrations: 2 entries each at most; OCRGPU_MAX_LAZY overrides the default bound
         u64 want = getenv("OCRGPU_MAX_LAZY") ? (u64)atoll(getenv("OCRGPU_MAX_LAZY")) : 4 * (u64)cfg->max_evt + 1024;
         if (want > (1ull << 22) && !getenv("OCRGPU_MAX_LAZY")) want = 1ull << 22;
@@ -1864,8 +1931,16 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     s.n_slots = e->n_slots;
     HIPCHK(hipMalloc((void **)&s.slots, 4 * (size_t)s.n_slots + 64));
     HIPCHK(hipMemcpyAsync(e->pinned_done + 33012, &d.ctrl->r_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33014, &d.ctrl->chan_wait_used, 8, hipMemcpyDeviceToHost, e->stream)); // + chan_sat_used
     HIPCHK(hipStreamSynchronize(e->stream));
     s.n_fired_entries = e->pinned_done[33012];
+    s.chan_wait_used = e->pinned_done[33014]; s.chan_sat_used = e->pinned_done[33015]; // CHANNEL rings in use
+    if (s.chan_wait_used > d.max_edges) s.chan_wait_used = (u32)d.max_edges;
+    if (s.chan_sat_used > d.chan_sat_cap) s.chan_sat_used = d.chan_sat_cap;
+    HIPCHK(hipMalloc((void **)&s.chan_wait, 8 * (size_t)s.chan_wait_used + 64));
+    HIPCHK(hipMalloc((void **)&s.chan_sat, 4 * (size_t)s.chan_sat_used + 64));
+    if (s.chan_wait_used) HIPCHK(hipMemcpyAsync(s.chan_wait, d.waiters + (d.max_edges - s.chan_wait_used), 8 * (size_t)s.chan_wait_used, hipMemcpyDeviceToDevice, e->stream));
+    if (s.chan_sat_used) HIPCHK(hipMemcpyAsync(s.chan_sat, d.chan_sat, 4 * (size_t)s.chan_sat_used, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMalloc((void **)&s.fired, 4 * (size_t)s.n_fired_entries + 16));
     HIPCHK(hipMalloc((void **)&s.ctrl, sizeof(Ctrl)));
     s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt; s.n_db = e->n_db; e->snap_pop_cursor = e->pop_cursor;
@@ -1890,6 +1965,8 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     HIPCHK(hipMemcpyAsync(d.evt, s.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     if (e->n_evt) HIPCHK(hipMemcpyAsync(d.counted, s.counted, 8 * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.lazy_tab, s.lazy_tab, 16 * (size_t)e->lazy_cap, hipMemcpyDeviceToDevice, e->stream));
+    if (s.chan_wait_used) HIPCHK(hipMemcpyAsync(d.waiters + (d.max_edges - s.chan_wait_used), s.chan_wait, 8 * (size_t)s.chan_wait_used, hipMemcpyDeviceToDevice, e->stream));
+    if (s.chan_sat_used) HIPCHK(hipMemcpyAsync(d.chan_sat, s.chan_sat, 4 * (size_t)s.chan_sat_used, hipMemcpyDeviceToDevice, e->stream));
     // pre-slot words carry the "satisfied" marks: overflow words go back to what they were (inline ones are in the lines)
     if (s.n_slots) HIPCHK(hipMemcpyAsync(d.slots, s.slots, 4 * (size_t)s.n_slots, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(d.fired, s.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));

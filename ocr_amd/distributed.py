@@ -62,7 +62,7 @@ class Partition:
         self.send = self.torch.zeros((world, cap, REC_BYTES), dtype=self.torch.uint8, device=f"cuda:{device}")
         self.eng = Engine(max_edt=max(n_my_edt, 1), max_evt=max(int((self.own_evt == rank).sum()), 1),
                           max_db=s.n_db + world * cap + 16,
-                          max_slots=int(s.edt["depc"][mine_e].sum()) + 1, max_edges=n_adddep + 1, device=device,
+                          max_slots=int(s.edt["depc"][mine_e].sum()) + 1, max_edges=n_adddep + 1 + ops.channel_ring_slots(s), device=device,
                           location=rank, flags=flags)
         self.eng.exchange_config(world, self.send.data_ptr(), cap, n_adddep + len(s.script) + 16)
         self.eng.set_hash_tag_base(s.n_db)
@@ -176,12 +176,14 @@ class Partition:
                         and np.array_equal(od, self.db_guid[s.n_db + idx]), "GUID prediction drifted (EDTs)"
                     self._created[idx] = True
             elif op == ops.OP_ADD_DEP:
-                so, do = self._owner_of_refs(blk["a"]), self._owner_of_refs(blk["b"])
-                m = np.where(so >= 0, so, do) == me
-                if m.any():
-                    b = blk[m]
-                    eng.add_dependence(self._guids(b["a"]), self._guids(b["b"]), b["slot"], b["mode"].astype(np.uint32))
-                yield op
+                for c0, c1 in (ops.split_conflicts(ops.channel_keys(s, blk["a"])) if ops.channel_ring_slots(s) else [(0, len(blk))]):   # registrations on one CHANNEL keep program order
+                    sub = blk[c0:c1]
+                    so, do = self._owner_of_refs(sub["a"]), self._owner_of_refs(sub["b"])
+                    m = np.where(so >= 0, so, do) == me
+                    if m.any():
+                        b = sub[m]
+                        eng.add_dependence(self._guids(b["a"]), self._guids(b["b"]), b["slot"], b["mode"].astype(np.uint32))
+                    yield op
             elif op == ops.OP_SATISFY:
                 for c0, c1 in ops.split_conflicts(blk["a"]):   # two satisfies of one event keep program order
                     sub = blk[c0:c1]

@@ -316,7 +316,7 @@ class StreamProgram:
         n_slots = int(s.edt["depc"].sum())
         n_adddep = int((s.main["op"] == ops.OP_ADD_DEP).sum())
         self.eng = engine or Engine(max_edt=max(s.n_edt, 1) + slack, max_evt=max(s.n_evt, 1), max_db=max(s.n_db, 1),
-                                    max_slots=n_slots + 1, max_edges=n_adddep + 1, device=device, flags=flags)
+                                    max_slots=n_slots + 1, max_edges=n_adddep + 1 + ops.channel_ring_slots(s), device=device, flags=flags)
         self.edt_guid = np.zeros(s.n_edt, np.uint64)
         self.evt_guid = np.zeros(s.n_evt_total, np.uint64)
         self.db_guid = np.zeros(s.n_db_total, np.uint64)
@@ -366,7 +366,9 @@ class StreamProgram:
                 self.edt_guid[idx], self.evt_guid[s.n_evt + idx], self.db_guid[s.n_db + idx] = g, oe, od
                 self.edt_order += idx.tolist()
             elif op == ops.OP_ADD_DEP:
-                eng.add_dependence(self._guids(blk["a"]), self._guids(blk["b"]), blk["slot"], blk["mode"].astype(np.uint32))
+                for c0, c1 in (ops.split_conflicts(ops.channel_keys(s, blk["a"])) if ops.channel_ring_slots(s) else [(0, len(blk))]):   # registrations on one CHANNEL keep program order
+                    b = blk[c0:c1]
+                    eng.add_dependence(self._guids(b["a"]), self._guids(b["b"]), b["slot"], b["mode"].astype(np.uint32))
             elif op == ops.OP_SATISFY:
                 for c0, c1 in ops.split_conflicts(blk["a"]):   # two satisfies of one event keep program order
                     b = blk[c0:c1]

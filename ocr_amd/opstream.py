@@ -379,6 +379,26 @@ class Builder:
                         name=self.name)
 
 
+def channel_ring_slots(s):
+    """waiters[] entries the engine sets aside for the rings of the stream's CHANNEL events (maxGen each; unbounded = 1024)"""
+    if not len(s.evt):
+        return 0
+    a = s.evt["arg"][s.evt["kind"] == EVT_CHANNEL].astype(np.int64)
+    return int(np.where(a > 0, a, 1024).sum())
+
+
+def channel_keys(s, src_refs):
+    """key per add-dependence op: its source ref when that is a CHANNEL event, else 0 -- for split_conflicts: two
+    registrations on one channel are two generations and must stay in program order"""
+    src_refs = np.asarray(src_refs, dtype=np.uint64)
+    keys = np.zeros(len(src_refs), np.uint64)
+    if len(s.evt):
+        m = ref_cls(src_refs) == REF_EVT
+        idx = ref_idx(src_refs[m]).astype(np.int64)
+        keys[m] = np.where(s.evt["kind"][idx] == EVT_CHANNEL, src_refs[m], np.uint64(0))
+    return keys
+
+
 def split_conflicts(keys):
     """Cut points for a run of ops so that no non-zero key repeats inside one sub-batch (ops of one batch are
     unordered on the GPU; two satisfies of the SAME event must stay in program order)."""

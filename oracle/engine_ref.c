@@ -42,7 +42,9 @@ enum { ST_LIVE = 0, ST_SAT = 1, ST_DESTROYED = 2, ST_ABSENT = 3 };
 enum { ERR_DOUBLE_SLOT = 0, ERR_ONCE_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_EVENT = 3, ERR_BAD_OP = 4, N_ERR = 8 };
 
 typedef struct { uint32_t dst, slot; uint8_t dst_is_evt, mode_null; } waiter_t;
-typedef struct { uint32_t kind, state; int32_t counter; uint32_t data; uint32_t n_w, cap_w; waiter_t *w; } event_t;
+/* CHANNEL: w[w_head..n_w) = registered waiters not yet paired, sq[sq_head..sq_n) = satisfies not yet paired (FIFO both) */
+typedef struct { uint32_t kind, state; int32_t counter; uint32_t data; uint32_t n_w, cap_w; waiter_t *w;
+                 uint32_t w_head, sq_head, sq_n, sq_cap, *sq; } event_t;
 typedef struct { uint32_t depc, cnt, frontier; uint64_t slot_base; uint8_t created; } edtst_t;
 /* lazy_evt: a persistent event (index+1) named by ocrAddDependence on which the EDT has NOT registered yet: it does
  * so only when its frontier -- the first pre-slot not yet satisfied -- reaches this slot (hc-task.c:1286-1338,1361-1410) */
@@ -146,6 +148,17 @@ static void drain(eng_t *E) {
             fan_out(E, v, w.payload);
             if (v->counter == 0) v->state = ST_DESTROYED;  /* :557,561 */
             break;
+        case OCREVT_CHANNEL: /* satisfyEventHcChannel hc-event.c:2125-2156: the oldest waiter takes it, else it queues */
+            if (v->w_head < v->n_w) {
+                waiter_t *cw = &v->w[v->w_head++];
+                work_t d = { cw->dst, cw->slot, w.payload, cw->dst_is_evt, cw->mode_null };
+                push_work(E, d);
+            } else {
+                if (v->counter > 0 && v->sq_n - v->sq_head >= (uint32_t)v->counter) { E->err[ERR_BAD_OP]++; break; } /* ASSERT :2023 */
+                if (v->sq_n == v->sq_cap) { v->sq_cap = v->sq_cap ? 2 * v->sq_cap : 4; v->sq = realloc(v->sq, 4 * (size_t)v->sq_cap); }
+                v->sq[v->sq_n++] = w.payload;
+            }
+            break;
         default: E->err[ERR_BAD_OP]++; break;
         }
     }
@@ -182,6 +195,17 @@ static void op_add_dep(eng_t *E, const ocrops_op_t *op) {
         return;
     }
     if (v->state == ST_DESTROYED || v->state == ST_ABSENT) { E->err[ERR_ONCE_LATE_WAITER]++; return; }
+    if (v->kind == OCREVT_CHANNEL) { /* registerWaiterEventHcChannel hc-event.c:2081-2123: takes the oldest queued satisfy, else waits in line */
+        if (v->sq_head < v->sq_n) {
+            work_t w = { dst, op->slot, v->sq[v->sq_head++], (uint8_t)dst_is_evt, mode_null };
+            push_work(E, w); drain(E);
+        } else {
+            if (v->counter > 0 && v->n_w - v->w_head >= (uint32_t)v->counter) { E->err[ERR_BAD_OP]++; return; } /* ASSERT :2005 */
+            waiter_t w = { dst, op->slot, (uint8_t)dst_is_evt, mode_null };
+            add_waiter(E, v, w);
+        }
+        return;
+    }
     if (v->state == ST_SAT) { /* persistent, already satisfied: immediate satisfy with stored data */
         work_t w = { dst, op->slot, v->data, (uint8_t)dst_is_evt, mode_null };
         /* registerWaiterEventHcCounted hc-event.c:1211-1238: the late registration is counted; the last one destroys */
@@ -257,7 +281,7 @@ int ocrref_run(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_
         const ocrops_op_t *op = &main_ops[k];
         switch (op->op) {
         case OCROP_EVT_CREATE: { event_t *v = &E.ev[op->a]; v->kind = evt[op->a].kind; v->state = ST_LIVE;
-                                  v->counter = (v->kind == OCREVT_LATCH || v->kind == OCREVT_COUNTED) ? evt[op->a].arg : 0; } break;
+                                  v->counter = (v->kind == OCREVT_LATCH || v->kind == OCREVT_COUNTED || v->kind == OCREVT_CHANNEL) ? evt[op->a].arg : 0; } break; /* CHANNEL: maxGen */
         case OCROP_DB_CREATE: E.db_val[op->a] = db_init[op->a]; E.db_live[op->a] = 1; break;
         case OCROP_EDT_CREATE: { uint32_t e = (uint32_t)op->a; E.ed[e].created = 1;
                                   if (edt[e].body & OCRBODY_F_OUTEVT) { event_t *v = &E.ev[h->n_evt + e]; v->kind = OCREVT_ONCE; v->state = ST_LIVE; }
@@ -283,9 +307,10 @@ int ocrref_run(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_
         case ST_ABSENT: evt_state[x] = OCREVS(OCREVS_ABSENT, 0); break;
         case ST_DESTROYED: evt_state[x] = OCREVS(OCREVS_DESTROYED, 0); break;
         case ST_SAT: evt_state[x] = OCREVS(OCREVS_LIVE_SAT, v->data); break;
-        default: evt_state[x] = OCREVS(OCREVS_LIVE_UNSAT, v->kind == OCREVT_LATCH ? (uint32_t)v->counter : 0); break;
+        default: evt_state[x] = OCREVS(OCREVS_LIVE_UNSAT, v->kind == OCREVT_LATCH ? (uint32_t)v->counter
+                                       : v->kind == OCREVT_CHANNEL ? ((v->sq_n - v->sq_head) << 16) | (v->n_w - v->w_head) : 0); break;
         }
-        free(v->w);
+        free(v->w); free(v->sq);
     }
     if (stats) { memset(stats, 0, 16 * 8); stats[0] = (uint64_t)lvl; stats[1] = fired; stats[2] = E.n_edge_sat; stats[3] = E.n_evt_sat;
                  for (int i = 0; i < N_ERR; ++i) stats[8 + i] = E.err[i]; }

@@ -47,6 +47,8 @@ static struct {
     uint64_t *slot_src;      /* [sum depc] source ref of each EDT pre-slot (0 = none/NULL/DB) */
     uint32_t *feed_ptr, *feed_idx; /* CSR: events feeding event x through ocrAddDependence(evt,evt) */
     volatile long long *clk; /* [n_evt_total] */
+    /* CHANNEL events pair their k-th satisfy with their k-th waiter (hc-event.c:2081-2156): one clock per generation */
+    long long **chan_clk; volatile uint32_t *chan_nsat; uint32_t *chan_nreg; uint32_t *slot_gen; /* slot_gen[pre-slot] = generation it waits for */
     int32_t *level; uint64_t *val;
     volatile uint32_t n_fired;
     const char *res_path; int guid_is_map;
@@ -101,6 +103,10 @@ static long long clk_resolve(uint32_t x) {
 static void do_satisfy(const ocrops_op_t *op, uint32_t self, long long lvl, ocrEdtDep_t *depv) {
     ocrGuid_t dst = ref_guid(op->a, self, depv), payload = ref_guid(op->b, self, depv);
     uint32_t c = OCRREF_CLS(op->a);
+    if (c == OCRREF_EVT && evt_kind(evt_index(op->a)) == OCREVT_CHANNEL) { /* streams keep one satisfier at a time per channel */
+        uint32_t x = evt_index(op->a);
+        G.chan_clk[x][__sync_fetch_and_add(&G.chan_nsat[x], 1)] = lvl;
+    } else
     if (c == OCRREF_EVT || c == OCRREF_OUTEVT) clk_note(evt_index(op->a), lvl);
     ocrEventSatisfySlot(dst, payload, op->slot);
 }
@@ -117,7 +123,8 @@ static ocrGuid_t bodyEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) 
         uint64_t s = G.slot_src[G.slot_base[id] + i];
         uint32_t c = OCRREF_CLS(s);
         if (c == OCRREF_EVT || c == OCRREF_OUTEVT) {
-            long long f = clk_resolve(evt_index(s));
+            long long f = evt_kind(evt_index(s)) == OCREVT_CHANNEL ? G.chan_clk[evt_index(s)][G.slot_gen[G.slot_base[id] + i]]
+                                                                  : clk_resolve(evt_index(s));
             if (f == CLK_UNSET) { fprintf(stderr, "replay: EDT %u slot %u fired before its source\n", id, i); abort(); }
             if (f + 1 > lvl) lvl = f + 1;
         }
@@ -169,6 +176,10 @@ static uint64_t dump_event_state(ocrPolicyDomain_t *pd, uint32_t x) {
     uint32_t k = evt_kind(x);
     if (k == OCREVT_LATCH) return OCREVS(OCREVS_LIVE_UNSAT, (uint32_t)((ocrEventHcLatch_t *)val)->counter);
     if (k == OCREVT_ONCE) return OCREVS(OCREVS_LIVE_UNSAT, 0);
+    if (k == OCREVT_CHANNEL) { /* queued satisfies and waiters not yet paired (hc-event.h:105-120) */
+        ocrEventHcChannel_t *c = (ocrEventHcChannel_t *)val;
+        return OCREVS(OCREVS_LIVE_UNSAT, ((c->tailSat - c->headSat) << 16) | (c->tailWaiter - c->headWaiter));
+    }
     ocrGuid_t d = ((ocrEventHcPersist_t *)val)->data; /* UNINITIALIZED_GUID until satisfied, hc-event.c:1616 */
     if (ocrGuidIsUninitialized(d)) return OCREVS(OCREVS_LIVE_UNSAT, 0);
     uint32_t did = 0;
@@ -214,6 +225,19 @@ static void load_stream(const char *path) {
     for (uint32_t i = 0; i < G.hdr.n_edt; ++i) G.slot_base[i + 1] = G.slot_base[i] + G.edt[i].depc;
     G.slot_src = calloc(G.slot_base[G.hdr.n_edt] + 1, 8);
     G.feed_ptr = calloc(G.n_evt_total + 2, 4);
+    G.slot_gen = calloc(G.slot_base[G.hdr.n_edt] + 1, 4);
+    G.chan_clk = calloc(G.n_evt_total + 1, sizeof(long long *));
+    G.chan_nsat = calloc(G.n_evt_total + 1, 4); G.chan_nreg = calloc(G.n_evt_total + 1, 4);
+    {   /* one clock per satisfy a channel can ever see */
+        uint32_t *cnt = calloc(G.n_evt_total + 1, 4);
+        for (uint32_t k = 0; k < G.hdr.n_main; ++k) if (G.main_ops[k].op == OCROP_SATISFY && OCRREF_CLS(G.main_ops[k].a) == OCRREF_EVT) cnt[OCRREF_IDX(G.main_ops[k].a)]++;
+        for (uint32_t k = 0; k < G.hdr.n_script; ++k) if (G.script[k].op == OCROP_SATISFY && OCRREF_CLS(G.script[k].a) == OCRREF_EVT) cnt[OCRREF_IDX(G.script[k].a)]++;
+        for (uint32_t x = 0; x < G.hdr.n_evt; ++x) if (G.evt[x].kind == OCREVT_CHANNEL) {
+            G.chan_clk[x] = malloc(8 * (cnt[x] + 1));
+            for (uint32_t k = 0; k <= cnt[x]; ++k) G.chan_clk[x][k] = CLK_UNSET;
+        }
+        free(cnt);
+    }
     /* static pre-pass over main: pre-slot sources and event->event feeders (CSR by destination) */
     uint32_t *cursor = NULL;
     for (int pass = 0; pass < 2; ++pass) {
@@ -222,10 +246,16 @@ static void load_stream(const char *path) {
             if (op->op != OCROP_ADD_DEP) continue;
             uint32_t sc = OCRREF_CLS(op->a), dc = OCRREF_CLS(op->b);
             int src_evt = (sc == OCRREF_EVT || sc == OCRREF_OUTEVT);
+            if (src_evt && evt_kind(evt_index(op->a)) == OCREVT_CHANNEL && dc != OCRREF_EDT) { fprintf(stderr, "replay: CHANNEL -> event dependences have no clock here\n"); abort(); }
             if (dc == OCRREF_EDT) {
-                if (!pass) { G.slot_src[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = op->a; G.n_sat_edges++; }
+                if (!pass) {
+                    G.slot_src[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = op->a; G.n_sat_edges++;
+                    if (src_evt && evt_kind(evt_index(op->a)) == OCREVT_CHANNEL)
+                        G.slot_gen[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = G.chan_nreg[evt_index(op->a)]++;
+                }
             } else if (src_evt && (dc == OCRREF_EVT || dc == OCRREF_OUTEVT)) {
                 uint32_t x = evt_index(op->b);
+                if (evt_kind(x) == OCREVT_CHANNEL) { fprintf(stderr, "replay: event -> CHANNEL dependences have no clock here\n"); abort(); }
                 if (!pass && evt_kind(x) == OCREVT_LATCH) G.n_sat_edges++;
                 if (!pass) G.feed_ptr[x + 1]++; else G.feed_idx[cursor[x]++] = evt_index(op->a);
             }
@@ -259,9 +289,11 @@ ocrGuid_t mainEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) {
         switch (op->op) {
         case OCROP_EVT_CREATE: {
             uint32_t x = (uint32_t)op->a; const ocrops_evt_t *ev = &G.evt[x];
-            if ((ev->kind == OCREVT_LATCH && ev->arg != 0) || ev->kind == OCREVT_COUNTED) {
+            if ((ev->kind == OCREVT_LATCH && ev->arg != 0) || ev->kind == OCREVT_COUNTED || ev->kind == OCREVT_CHANNEL) {
                 ocrEventParams_t p; memset(&p, 0, sizeof p);
-                if (ev->kind == OCREVT_LATCH) p.EVENT_LATCH.counter = ev->arg; else p.EVENT_COUNTED.nbDeps = ev->arg;
+                if (ev->kind == OCREVT_LATCH) p.EVENT_LATCH.counter = ev->arg;
+                else if (ev->kind == OCREVT_COUNTED) p.EVENT_COUNTED.nbDeps = ev->arg;
+                else { p.EVENT_CHANNEL.maxGen = (u32)ev->arg; p.EVENT_CHANNEL.nbSat = 1; p.EVENT_CHANNEL.nbDeps = 1; } /* the only shape supported, hc-event.c:1629 */
                 ocrEventCreateParams(&G.evt_guid[x], (ocrEventTypes_t)ev->kind, EVT_PROP_TAKES_ARG, &p);
             } else
                 ocrEventCreate(&G.evt_guid[x], (ocrEventTypes_t)ev->kind, EVT_PROP_TAKES_ARG);

@@ -8,7 +8,7 @@ Every stream is well formed: its outcome does not depend on the schedule.
 """
 import numpy as np
 
-from ocr_amd.opstream import (BODY_FWD0, BODY_HASH, BODY_NOP, EVT_COUNTED, EVT_IDEM, EVT_LATCH, EVT_ONCE, EVT_STICKY,
+from ocr_amd.opstream import (BODY_FWD0, BODY_HASH, BODY_NOP, EVT_CHANNEL, EVT_COUNTED, EVT_IDEM, EVT_LATCH, EVT_ONCE, EVT_STICKY,
                               LATCH_DECR, LATCH_INCR, MODE_NULL, MODE_RO, MODE_RW, Builder, cholesky_dag, layered_dag,
                               powerlaw_dag, stencil_dag)
 
@@ -275,15 +275,48 @@ def wide_fanin():
     return b.finish(prods + [big] + fan, start)
 
 
-SEMANTIC = [latch_decr_then_incr, latch_incr2_decr2, latch_init_counter, once_no_waiters, sticky_early_and_late,
+def channel_events():
+    """CHANNEL events (hc-event.c:2081-2156): the k-th satisfy goes to the k-th registered waiter, whichever comes
+    first; satisfies with nobody waiting queue up, waiters with nothing queued wait in line."""
+    b = Builder("channel_events")
+    start = b.evt(EVT_ONCE)
+    d0, d1 = b.db(500), b.db(501)
+    ch = b.evt(EVT_CHANNEL, 4)
+    b.satisfy(ch, d0)                               # generation 0 queued before anybody waits
+    a = b.edt(2, BODY_HASH)
+    b.add_dep(start, a, 0)
+    b.add_dep(ch, a, 1)                             # takes generation 0 at once
+    bb = b.edt(2, BODY_HASH)
+    b.add_dep(start, bb, 0)
+    b.add_dep(ch, bb, 1)                            # waits for generation 1
+    c = b.edt(3, BODY_HASH)
+    b.add_dep(start, c, 0)
+    b.add_dep(ch, c, 2, MODE_NULL)                  # generation 2, payload dropped by the mode
+    b.add_dep(d1, c, 1)
+    drv = b.edt(1, BODY_NOP)
+    b.add_dep(start, drv, 0)
+    b.script_satisfy(drv, ch, d1)                   # generation 1 -> bb (level 1)
+    b.script_satisfy(bb, ch, b.outdb(bb))           # generation 2 -> c  (level 2)
+    q = b.evt(EVT_CHANNEL, 2)                       # two satisfies nobody takes
+    b.satisfy(q, d0)
+    b.satisfy(q, 0)
+    w = b.evt(EVT_CHANNEL, 2)                       # a waiter nobody serves
+    never = b.edt(1, BODY_NOP)
+    b.add_dep(w, never, 0)
+    gone = b.evt(EVT_CHANNEL, 1)
+    b.destroy(gone)
+    return b.finish([a, bb, c, drv], start)
+
+
+SEMANTIC = [channel_events, latch_decr_then_incr, latch_incr2_decr2, latch_init_counter, once_no_waiters, sticky_early_and_late,
             counted_events, idem_double_satisfy, mode_null_forces_null, db_and_null_sources, event_chain, forward_and_nop,
             destroy_and_unfired, wide_fanin]
 
 
 def random_stream(seed, n=36, eager_safe=False):
     """A random WELL-FORMED OCR program (no user errors, no payload races): every kind of source on EDT pre-slots
-    (start event, datablocks, NULL_GUID, output events, ONCE / STICKY / IDEM / COUNTED / LATCH events driven by EDT
-    scripts, by main, by other events, or by nobody), inline and overflow pre-slots, all three bodies, all payload
+    (start event, datablocks, NULL_GUID, output events, ONCE / STICKY / IDEM / COUNTED / LATCH / CHANNEL events driven by
+    EDT scripts, by main, by other events, or by nobody), inline and overflow pre-slots, all three bodies, all payload
     kinds.  Used as fuzz input: reference runtime == restatement on every seed.
     eager_safe=True keeps COUNTED events off pre-slots the EDT's frontier may never reach: the reference registers an
     EDT on a persistent event only when all earlier pre-slots are satisfied (hc-task.c:1286-1338), the GPU engine
@@ -354,6 +387,31 @@ def random_stream(seed, n=36, eager_safe=False):
         ev["fires"] = d[1]
         return ev
 
+    chans = []         # CHANNEL events: only on pre-slots k > 0; satisfied by main (early and late) and by at most ONE body
+
+    def channel_source(driver_pool):
+        """A CHANNEL event for the next waiter and whether that waiter will be served.  Generation g of a channel goes
+        to its g-th registered waiter: main's early satisfies first, then main's late ones, then the one body's."""
+        ch = chans[int(rng.integers(len(chans)))] if chans and rng.integers(2) else None
+        if ch is None:
+            ch = {"ref": b.evt(EVT_CHANNEL, 8), "early": int(rng.integers(0, 3)), "late": int(rng.integers(0, 2)), "drv": None, "regs": 0}
+            for _ in range(ch["early"]):
+                b.satisfy(ch["ref"], dbs[int(rng.integers(len(dbs)))] if rng.integers(2) else 0)
+            for _ in range(ch["late"]):
+                late.append(("sat", ch, dbs[int(rng.integers(len(dbs)))] if rng.integers(2) else 0))
+            if driver_pool and rng.integers(3):
+                d = driver_pool[int(rng.integers(len(driver_pool)))]
+                pay = pick_payload(d[2], (d[4] & 0xFF) == BODY_HASH)
+                b.script_satisfy(d[0], ch["ref"], b.outdb(d[0]) if pay == "outdb" else pay)
+                ch["drv"] = d
+            chans.append(ch)
+        g = ch["regs"]
+        ch["regs"] += 1
+        if ch["regs"] > 7:
+            chans.remove(ch)                                   # stay below maxGen waiters in line
+        served = g < ch["early"] + ch["late"] or (g == ch["early"] + ch["late"] and ch["drv"] is not None and ch["drv"][1])
+        return ch["ref"], served
+
     for i in range(n):
         depc = int([1, 1, 1, 2, 2, 3, 4, 6, 7, 9][int(rng.integers(10))])   # never 0: such an EDT would run while main still builds
         body = [BODY_HASH, BODY_HASH, BODY_NOP, BODY_FWD0][int(rng.integers(4))]
@@ -367,7 +425,11 @@ def random_stream(seed, n=36, eager_safe=False):
             t = int(rng.integers(0, 12)) if k else [0, 0, 5, 9][int(rng.integers(4))]
             mode = MODE_NULL if rng.integers(4) == 0 else MODE_RO
             outs = [x for x in edts if x[3] and x[2] > 0]
-            if t <= 1:
+            if k and rng.integers(10) == 0:
+                cref, served = channel_source(drivers)
+                b.add_dep(cref, e, k, mode)
+                fires &= served
+            elif t <= 1:
                 b.add_dep(start, e, k, mode)
             elif t == 2:
                 b.add_dep(dbs[int(rng.integers(len(dbs)))], e, k, mode)
@@ -393,6 +455,9 @@ def random_stream(seed, n=36, eager_safe=False):
     # event -> event dependences, after every EDT registration; newest first, so that a destination has all of its
     # own waiters before a source that main already satisfied fires (and, if ONCE, destroys) it
     for what, src, dst in reversed(late):
+        if what == "sat":                                      # a late main satisfy of a CHANNEL: the waiters are in line by now
+            b.satisfy(src["ref"], dst)
+            continue
         slot = LATCH_DECR if dst["kind"] == EVT_LATCH else 0
         b.add_dep(src["ref"], dst["ref"], slot, MODE_RO)
     for ev in events:                                          # COUNTED: nbDeps = the registrations it will see
