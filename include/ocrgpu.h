@@ -109,7 +109,12 @@ int ocrgpu_guid_remove(ocrgpu_engine_t *e, uint64_t n, const uint64_t *guids, in
 /* ---- object creation (replace newEventHc hc-event.c:1558-1765, newTaskHc hc-task.c:871-1136,
  *      hcAllocateDb hc-policy.c:752-784).  Objects get engine indices in creation order;
  *      ocrgpu_guid_get() on an engine-made guid returns (index + 1).                       ------ */
-/* ocrEventCreateParams (ocr-edt.c:19): kind = ocrEventTypes_t 1..4; arg = LATCH initial counter */
+/* ocrEventCreateParams (ocr-edt.c:19): kind = ocrEventTypes_t 1..6; arg = LATCH initial counter (hc-event.c:1700),
+ * COUNTED nbDeps > 0 (:1600-1612), CHANNEL maxGen = generations that may be in flight (nbSat = nbDeps = 1, the only
+ * shape the reference supports, :1629; <= 0 = EVENT_CHANNEL_UNBOUNDED, held to 1024 here).  A CHANNEL pairs its k-th
+ * satisfy with its k-th registered waiter (:2081-2156); satisfies of one channel issued in ONE call (or by bodies of
+ * one level) take their generations in no particular order, as concurrent workers do in the reference; callers that
+ * need an order use separate calls.  Each CHANNEL takes maxGen entries of max_edges. */
 int ocrgpu_event_create(ocrgpu_engine_t *e, uint64_t n, const uint32_t *kind, const int32_t *arg,
                         uint64_t *guids_out, int where);
 /* ocrDbCreate (ocr-db.h:78): a DB here is a 16-byte payload {value, tag}                    */
