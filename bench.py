@@ -64,7 +64,7 @@ def main():
 
     # ---- build: every rank owns one partition = one independent layered DAG (seeded per rank) ----
     seed = opstream.SEED_BASE + 2 + 1000 * rank
-    s = opstream.layered_dag(args.n_edt, args.width, seed=seed, _exp_no_leaf_latch=bool(os.environ.get("OCRGPU_EXP_NO_LEAF_LATCH")))
+    s = opstream.layered_dag(args.n_edt, args.width, seed=seed)
     start_op = s.main[-1:]                      # the final ocrEventSatisfy(start)
     built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
     t0 = time.time()

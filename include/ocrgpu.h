@@ -73,6 +73,10 @@ typedef struct {
     uint32_t max_levels;   /* level boundaries recorded (0 = 1<<20)                           */
     uint32_t flags;        /* OCRGPU_F_*                                                      */
 } ocrgpu_config_t;
+/* Environment overrides read by ocrgpu_init (capacities the config struct has no field for, and two launch-shape
+ * knobs kept for measurements): OCRGPU_MAX_LAZY (held-back COUNTED registrations, default 4*max_evt+1024, at most 4M),
+ * OCRGPU_CHAN_SLOTS (queued CHANNEL payloads, default min(max_edges, 4M)), OCRGPU_SPREAD_WGS (workgroups a short work
+ * list is dealt over, default 256), OCRGPU_STEP_GRID (grid of a step launch, default 2048). */
 #define OCRGPU_F_NANNY 1u  /* detect double satisfy of an EDT pre-slot (hc-task.c:1243); +1 atomic per edge */
 #define OCRGPU_F_TIMING 2u /* bracket resolve's kernels with HIP events on the engine stream   */
 

@@ -215,7 +215,7 @@ def splitmix64(seed: int, n: int, offset: int = 0) -> np.ndarray:
 SEED_BASE = 0x0C5200000000  # seed = 0x0C5200000000 + config#
 
 
-def layered_dag(n_edt: int, width: int, seed: int = SEED_BASE + 2, name=None, _exp_no_leaf_latch=False) -> OpStream:
+def layered_dag(n_edt: int, width: int, seed: int = SEED_BASE + 2, name=None) -> OpStream:
     """BASELINE config 2: layered random DAG with ONCE output events.
 
     ``n_edt`` EDTs in ``n_edt/width`` layers of ``width``.  An EDT in layer l>0 has
@@ -251,8 +251,6 @@ def layered_dag(n_edt: int, width: int, seed: int = SEED_BASE + 2, name=None, _e
     consumed = np.zeros(N, dtype=bool)
     consumed[src] = True
     leaves = np.nonzero(~consumed)[0]
-    if _exp_no_leaf_latch:  # timing experiment only: only the last layer feeds the sink latch
-        leaves = np.arange(N - width, N)
     n_leaves = len(leaves)
 
     EV_START, EV_LATCH = 0, 1
