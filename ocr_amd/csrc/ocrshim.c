@@ -369,42 +369,6 @@ u8 ocrGetHintValue(ocrHint_t *h, ocrHintProp_t p, u64 *v) {
 u8 ocrSetHint(ocrGuid_t guid, ocrHint_t *h) { (void)guid; return h ? 0 : OCR_EINVAL; }
 u8 ocrGetHint(ocrGuid_t guid, ocrHint_t *h) { (void)guid; if (!h) return OCR_EINVAL; h->propMask = 0; return 0; }
 
-/* ---- CHANNEL events (ocr/src/event/hc/hc-event.c:2081-2156), kept on the host: a channel pairs its satisfies with
- *      its waiters in FIFO order, one to one (nbSat = nbDeps = 1, hc-event.c:1629-1630), so it never needs a fan-out;
- *      each pairing is handed to the engine as the add-dependence "datablock -> waiter slot", which satisfies it. ---- */
-typedef struct { u64 a; u32 slot, round; u8 mode; u64 epoch; } ChanItem;   /* a = datablock (satisfy) or destination (waiter) */
-typedef struct { ChanItem *sat, *wait; size_t n_sat, h_sat, cap_sat, n_wait, h_wait, cap_wait; u8 dead; } Channel;
-static Channel *chans; static size_t n_chan, cap_chan;
-static Channel *chan_of(u64 g) {
-    if (OCRGPU_GUID_KIND(g) != OCRGPU_KIND_EVT_CHANNEL || OCRGPU_GUID_COUNTER(g) == 0 || OCRGPU_GUID_COUNTER(g) > n_chan) return NULL;
-    return &chans[OCRGPU_GUID_COUNTER(g) - 1];
-}
-/* the pairing's add-dependence must reach the engine after whatever created its datablock / destination, even when
- * that was queued by another EDT of this level */
-static void chan_deliver(const ChanItem *sat, const ChanItem *wait) {
-    const ChanItem *it[2] = { sat, wait };
-    for (int k = 0; k < 2; ++k)
-        if (it[k]->epoch == flush_epoch && it[k]->round > cur_round) { cur_round = it[k]->round; cur_cls = C_ADD_DEP; n_touched = 0; }
-    Op *o = emit(C_ADD_DEP);
-    o->a = sat->a; o->b = wait->a; o->slot = wait->slot; o->mode = wait->mode;
-}
-static u8 chan_satisfy(Channel *c, u64 db) {
-    if (c->dead) return OCR_EINVAL;
-    ChanItem s = { db, 0, cur_round, 0, flush_epoch };
-    if (c->h_wait < c->n_wait) { chan_deliver(&s, &c->wait[c->h_wait++]); return 0; }
-    GROW(c->sat, c->n_sat, c->cap_sat);
-    c->sat[c->n_sat++] = s;
-    return 0;
-}
-static u8 chan_add_waiter(Channel *c, u64 dst, u32 slot, u8 mode) {
-    if (c->dead) return OCR_EINVAL;
-    ChanItem w = { dst, slot, cur_round, mode, flush_epoch };
-    if (c->h_sat < c->n_sat) { chan_deliver(&c->sat[c->h_sat++], &w); return 0; }
-    GROW(c->wait, c->n_wait, c->cap_wait);
-    c->wait[c->n_wait++] = w;
-    return 0;
-}
-
 /* ---- the OCR API -------------------------------------------------------------------------------------------- */
 static u32 evt_guid_kind(ocrEventTypes_t t) {
     switch (t) {
@@ -413,51 +377,49 @@ static u32 evt_guid_kind(ocrEventTypes_t t) {
     case OCR_EVENT_STICKY_T: return OCRGPU_KIND_EVT_STICKY;
     case OCR_EVENT_LATCH_T: return OCRGPU_KIND_EVT_LATCH;
     case OCR_EVENT_COUNTED_T: return OCRGPU_KIND_EVT_COUNTED;
+    case OCR_EVENT_CHANNEL_T: return OCRGPU_KIND_EVT_CHANNEL;
     default: return 0;
     }
 }
 u8 ocrEventCreateParams(ocrGuid_t *guid, ocrEventTypes_t type, u16 properties, ocrEventParams_t *params) {
     u32 gk = evt_guid_kind(type);
     if (!guid) return OCR_EINVAL;
-    if (type == OCR_EVENT_CHANNEL_T) {
-        if (params && (params->EVENT_CHANNEL.nbSat != 1 || params->EVENT_CHANNEL.nbDeps != 1)) return OCR_ENOTSUP; /* as hc-event.c:1629-1630 */
-        GROW(chans, n_chan, cap_chan);
-        memset(&chans[n_chan], 0, sizeof chans[n_chan]);
-        guid->guid = (intptr_t)(((u64)OCRGPU_KIND_EVT_CHANNEL << 49) | (u64)(++n_chan));
-        return 0;
+    if (type == OCR_EVENT_CHANNEL_T && params && (params->EVENT_CHANNEL.nbSat != 1 || params->EVENT_CHANNEL.nbDeps != 1)) {
+        guid->guid = -1; return OCR_ENOTSUP; /* as hc-event.c:1629-1630 */
     }
-    if (!gk) { guid->guid = -1; return OCR_ENOTSUP; } /* CHANNEL: s8f item 3, not on the engine yet */
+    if (!gk) { guid->guid = -1; return OCR_ENOTSUP; }
     if (type == OCR_EVENT_COUNTED_T && (!params || params->EVENT_COUNTED.nbDeps == 0 || params->EVENT_COUNTED.nbDeps > 0xFFFF)) { guid->guid = -1; return OCR_EINVAL; }
     u64 lg; u8 lr = labeled_guid(guid, properties, gk, C_EVT_CREATE, &lg);
     if (lr) return lr;
     Op *o = emit(C_EVT_CREATE);
     o->a = lg ? lg : pool_take(gk); o->slot = (u32)type;
     o->arg = (type == OCR_EVENT_LATCH_T && params) ? (s32)params->EVENT_LATCH.counter        /* hc-event.c:1579-1589 */
-           : type == OCR_EVENT_COUNTED_T ? (s32)params->EVENT_COUNTED.nbDeps : 0;            /* hc-event.c:1600-1612 */
+           : type == OCR_EVENT_COUNTED_T ? (s32)params->EVENT_COUNTED.nbDeps                 /* hc-event.c:1600-1612 */
+           : (type == OCR_EVENT_CHANNEL_T && params && params->EVENT_CHANNEL.maxGen != EVENT_CHANNEL_UNBOUNDED) ? (s32)params->EVENT_CHANNEL.maxGen
+           : 0;                                                                              /* CHANNEL: 0 = unbounded */
     guid->guid = (intptr_t)o->a;
     return 0;
 }
 u8 ocrEventCreate(ocrGuid_t *guid, ocrEventTypes_t type, u16 properties) { return ocrEventCreateParams(guid, type, properties, NULL); }
 u8 ocrEventDestroy(ocrGuid_t guid) {
-    Channel *c = chan_of((u64)guid.guid);
-    if (c) { c->dead = 1; return 0; }
     Op *o = emit(C_EVT_DESTROY); o->a = (u64)guid.guid; labset_release(o->a);
     return 0;
 }
 u8 ocrEventSatisfySlot(ocrGuid_t evt, ocrGuid_t db, u32 slot) {
     if (ocrGuidIsNull(evt)) return 0; /* ocr-edt.c:171 */
-    Channel *c = chan_of((u64)evt.guid);
-    if (c) return chan_satisfy(c, (u64)db.guid);
     emit_satisfy((u64)evt.guid, (u64)db.guid, slot);
     return 0;
 }
 u8 ocrEventSatisfy(ocrGuid_t evt, ocrGuid_t db) { return ocrEventSatisfySlot(evt, db, 0); }
 u8 ocrAddDependence(ocrGuid_t src, ocrGuid_t dst, u32 slot, ocrDbAccessMode_t mode) {
-    Channel *c = chan_of((u64)src.guid);
-    if (c) return chan_add_waiter(c, (u64)dst.guid, slot, (u8)mode);
-    if (chan_of((u64)dst.guid)) return OCR_ENOTSUP; /* an event feeding a channel would need the channel on the engine */
+    const u64 sg = (u64)src.guid;
+    const int chan = sg != 0 && sg < (u64)-2 && OCRGPU_GUID_KIND(sg) == OCRGPU_KIND_EVT_CHANNEL;
+    if (chan) /* registrations on one CHANNEL are its generations (hc-event.c:2081-2123): one per engine call, in program order */
+        for (size_t i = 0; i < n_touched; ++i)
+            if (touched[i].evt == sg) { ++cur_round; n_touched = 0; cur_cls = -1; break; }
     Op *o = emit(C_ADD_DEP);
-    o->a = (u64)src.guid; o->b = (u64)dst.guid; o->slot = slot; o->mode = (u8)mode;
+    o->a = sg; o->b = (u64)dst.guid; o->slot = slot; o->mode = (u8)mode;
+    if (chan) { GROW(touched, n_touched, cap_touched); touched[n_touched].evt = sg; touched[n_touched].slot = 0xFFFFFFFFu; ++n_touched; }
     return 0;
 }
 
