@@ -38,8 +38,14 @@ def test_restatement_matches_reference_digests(safe, fuzz):
 def test_restatement_matches_live_reference_on_fresh_seeds(workers):
     for seed in range(1000, 1024):
         s = streams.random_stream(seed, n=48)
-        ref, _ = O.run_reference(s, workers=workers)
-        assert O.run_restatement(s).diff(ref) == [], s.name
+        for attempt in range(3):
+            try:                       # a run that dies is the reference's own trouble (its runtime does crash now and then,
+                ref, _ = O.run_reference(s, workers=workers)   # e.g. edtExecuteStickySync); a run that ends must agree
+                break
+            except RuntimeError:
+                if attempt == 2:
+                    raise
+        assert O.run_restatement(s).diff(ref) == [], (s.name, workers)
 
 
 def test_lazy_frontier_is_visible_in_a_counted_event():
