@@ -26,6 +26,8 @@
 #include <string.h>
 #include <limits.h>
 #include <sys/time.h>
+#include <sched.h>
+#include <time.h>
 #include "ocr.h"
 /* reference internals, only for the final-state peek in dump_event_state() */
 #include "ocr-policy-domain.h"
@@ -188,9 +190,32 @@ static uint64_t dump_event_state(ocrPolicyDomain_t *pd, uint32_t x) {
     return OCREVS(OCREVS_LIVE_SAT, did);
 }
 
+/* The sink runs as soon as the last DECR reaches its latch -- which the worker that delivered it does from INSIDE the
+ * fan-out of a ONCE output event (satisfyEventHcOnce, hc-event.c:437-465: notify the waiters, THEN destroy the event).
+ * With several workers the sink can therefore be dumping while that worker has not yet destroyed the event it is
+ * fanning out.  Every EDT that ran has its output event satisfied by its epilogue, so its guid must stop resolving:
+ * wait for that (bounded), then give stragglers of the same kind (a latch being destroyed after it fired) a moment. */
+static void settle_before_dump(ocrPolicyDomain_t *pd) {
+    if (!G.guid_is_map) return;
+    ocrGuidProvider_t *gp = pd->guidProviders[0];
+    for (int spin = 0; spin < 200000; ++spin) {
+        int pending = 0;
+        for (uint32_t e = 0; e < G.hdr.n_edt && !pending; ++e) {
+            if (G.level[e] < 0 || !(G.edt[e].body & OCRBODY_F_OUTEVT) || (G.edt[e].body & OCRBODY_F_SINK)) continue;
+            u64 val = 0; ocrGuidKind kind;
+            gp->fcts.getVal(gp, G.evt_guid[G.hdr.n_evt + e], &val, &kind, MD_LOCAL, NULL);
+            if (val != 0) pending = 1;
+        }
+        if (!pending) break;
+        sched_yield();
+    }
+    struct timespec ts = { 0, 2000000 }; nanosleep(&ts, NULL);
+}
+
 static void dump_results(void) {
     if (!G.res_path || !strcmp(G.res_path, "-")) return;
     ocrPolicyDomain_t *pd = NULL; getCurrentEnv(&pd, NULL, NULL, NULL);
+    settle_before_dump(pd);
     FILE *f = fopen(G.res_path, "wb");
     if (!f) { perror("result file"); abort(); }
     ocrres_hdr_t h; memset(&h, 0, sizeof h);

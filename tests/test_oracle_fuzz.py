@@ -45,7 +45,12 @@ def test_restatement_matches_live_reference_on_fresh_seeds(workers):
             except RuntimeError:
                 if attempt == 2:
                     raise
-        assert O.run_restatement(s).diff(ref) == [], (s.name, workers)
+        want = O.run_restatement(s)
+        if workers > 1 and want.diff(ref) != []:
+            # the record is dumped by the sink EDT while other workers may still be inside the call that released it
+            # (oracle/ocr_replay.c settle_before_dump narrows that window, it cannot close it): one more run decides
+            ref, _ = O.run_reference(s, workers=workers)
+        assert want.diff(ref) == [], (s.name, workers)
 
 
 def test_lazy_frontier_is_visible_in_a_counted_event():
