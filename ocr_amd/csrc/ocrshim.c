@@ -116,7 +116,9 @@ static u64 cur_scope;             /* latch of the finish scope children are crea
 static u32 pending_checkins;      /* children created in cur_scope by this body: INCRs issued when the body returns */
 static size_t body_first_task;    /* tasks[body_first_task..] were created by the running body */
 
+static void els_reset(void);
 static void body_begin(Task *t) {
+    els_reset();
     cur_round = 0; cur_cls = -1; n_touched = 0; cur_task = t; pending_checkins = 0; body_first_task = n_task;
     cur_scope = t ? (t->own_latch ? t->own_latch : t->scope_latch) : 0;
 }
@@ -368,6 +370,17 @@ u8 ocrGetHintValue(ocrHint_t *h, ocrHintProp_t p, u64 *v) {
 }
 u8 ocrSetHint(ocrGuid_t guid, ocrHint_t *h) { (void)guid; return h ? 0 : OCR_EINVAL; }
 u8 ocrGetHint(ocrGuid_t guid, ocrHint_t *h) { (void)guid; if (!h) return OCR_EINVAL; h->propMask = 0; return 0; }
+
+/* ---- runtime interface extension (ocr/inc/extensions/ocr-runtime-itf.h): one worker, EDT-local storage per body ---- */
+#include "extensions/ocr-runtime-itf.h"
+static ocrGuid_t els_slots[OCRSHIM_ELS_SLOTS];   /* cleared by body_begin */
+static void els_reset(void) { memset(els_slots, 0, sizeof els_slots); }
+ocrGuid_t ocrElsUserGet(u8 offset) { return offset < OCRSHIM_ELS_SLOTS ? els_slots[offset] : NULL_GUID; }
+void ocrElsUserSet(u8 offset, ocrGuid_t data) { if (offset < OCRSHIM_ELS_SLOTS) els_slots[offset] = data; }
+void currentEdtUserGet(ocrGuid_t *guid) { if (guid) guid->guid = cur_task ? (intptr_t)cur_task->guid : 0; }
+u64 ocrNbWorkers(void) { return 1; }
+void ocrCurrentWorkerGuid(ocrGuid_t *guid) { if (guid) guid->guid = (intptr_t)(((u64)OCRGPU_KIND_EDT - 1) << 49 | 1); } /* a fixed, non-null handle */
+u8 ocrInformLegacyCodeBlocking(void) { return 0; }
 
 /* ---- the OCR API -------------------------------------------------------------------------------------------- */
 static u32 evt_guid_kind(ocrEventTypes_t t) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE -- the reference's own non-regression programs as known-answer tests for libocrshim.
 
-Each program under /root/reference/ocr/tests/non-regression-tests/{events,finish,edt,datablock} is compiled twice from
+Each program under /root/reference/ocr/tests/non-regression-tests/{DIRS below} is compiled twice from
 the source where it lies (nothing is copied): against the reference runtime (oracle/_ref/libocr_x86_dbg.a) into
 oracle/_ref/reftests/, and against include/ocr_shim/ocr.h + libocrshim.a + libocrgpu.so into oracle/_ref/shimtests/.
 The reference build is run HERE (1 HC worker) and its exit code and console output are written to
@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = "/root/reference/ocr"
 TESTS = os.path.join(REF, "tests", "non-regression-tests")
-DIRS = ["events", "finish", "edt", "datablock", "guidlabel", "dist", "lifecycle"]
+DIRS = ["events", "finish", "edt", "datablock", "guidlabel", "dist", "lifecycle", "rtapi"]
 ARGS = {"testGuidLabelFib": ["12"]}          # command-line arguments a program needs
 # programs whose console lines depend on which of two concurrent EDTs wins a labeled create: only exit code and
 # PASSED/FAILURE lines are compared
@@ -56,7 +56,7 @@ def build_ref(src, out):
 
 def build_shim(src, out):
     cmd = ["gcc", "-O1", "-w", "-std=gnu11", "-DENABLE_EXTENSION_PARAMS_EVT", "-DENABLE_EXTENSION_COUNTED_EVT",
-           "-DENABLE_EXTENSION_LABELING", "-DENABLE_EXTENSION_AFFINITY", "-DENABLE_EXTENSION_CHANNEL_EVT", "-I", os.path.join(ROOT, "include", "ocr_shim"), "-I", os.path.join(ROOT, "include"),
+           "-DENABLE_EXTENSION_LABELING", "-DENABLE_EXTENSION_AFFINITY", "-DENABLE_EXTENSION_CHANNEL_EVT", "-DENABLE_EXTENSION_RTITF", "-I", os.path.join(ROOT, "include", "ocr_shim"), "-I", os.path.join(ROOT, "include"),
            src, os.path.join(ROOT, "ocr_amd", "libocrshim.a"), "-L", os.path.join(ROOT, "ocr_amd"), "-locrgpu",
            "-Wl,-rpath,$ORIGIN/../../../ocr_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", out]
     return subprocess.run(cmd, capture_output=True, text=True).returncode == 0
