@@ -102,6 +102,11 @@ static void *dbmap_take(u64 g) {
     return NULL;
 }
 
+/* a payload carries its length 16 bytes in front of it (ocrLegacyBlockProgress reports it) */
+static void *db_alloc(u64 len) { char *b = calloc(1, 16 + (len ? len : 1)); if (!b) return NULL; *(u64 *)b = len; return b + 16; }
+static void db_free(void *p) { if (p) free((char *)p - 16); }
+static u64 db_len(const void *p) { return p ? *(const u64 *)((const char *)p - 16) : 0; }
+
 /* ---- the deferred-op queue ---------------------------------------------------------------------------------- */
 enum { C_EVT_CREATE, C_DB_CREATE, C_EDT_CREATE, C_ADD_DEP, C_SATISFY, C_EVT_DESTROY, C_DB_DESTROY, N_CLASS };
 typedef struct { u8 cls, mode; u16 pad; u32 slot; u32 round; s32 arg; u64 a, b, c; u64 seq; } Op;
@@ -116,6 +121,7 @@ static u64 cur_scope;             /* latch of the finish scope children are crea
 static u32 pending_checkins;      /* children created in cur_scope by this body: INCRs issued when the body returns */
 static size_t body_first_task;    /* tasks[body_first_task..] were created by the running body */
 
+static u64 init_epoch;            /* bumped by every bring-up (legacy blocks bring the runtime up more than once) */
 static void els_reset(void);
 static void body_begin(Task *t) {
     els_reset();
@@ -165,6 +171,14 @@ static void body_end(Task *t, u64 ret) {
     if (!t) return;
     if (t->own_latch) emit_satisfy(t->own_latch, ret, OCRLATCH_DECR);
     else if (t->scope_latch) emit_satisfy(t->scope_latch, 0, OCRLATCH_DECR);
+}
+
+/* the body is about to wait (ocrLegacyBlockProgress): the children it created so far check in now, so that none of
+ * them can check out of the scope first; its own check-out still waits for body_end */
+static void body_pause(void) {
+    const u32 in = pending_checkins;
+    pending_checkins = 0;
+    if (in && cur_scope) emit_satisfy(cur_scope, 0, in == 1 ? OCRLATCH_INCR : OCRGPU_LATCH_DELTA((s32)in));
 }
 
 static int op_cmp(const void *x, const void *y) {
@@ -241,7 +255,7 @@ static void flush(void) {
             CHK(ocrgpu_event_destroy(G, n, bu64[0], OCRGPU_HOST));
             break;
         case C_DB_DESTROY:
-            for (size_t k = 0; k < n; ++k) { bu64[0][k] = o[k].a; free(dbmap_take(o[k].a)); }
+            for (size_t k = 0; k < n; ++k) { bu64[0][k] = o[k].a; db_free(dbmap_take(o[k].a)); }
             CHK(ocrgpu_guid_remove(G, n, bu64[0], OCRGPU_HOST));
             break;
         }
@@ -441,7 +455,7 @@ u8 ocrDbCreate(ocrGuid_t *db, void **addr, u64 len, u16 flags, ocrHint_t *hint, 
     if (!db || !addr) return OCR_EINVAL;
     u64 lg; u8 lr = labeled_guid(db, flags, OCRGPU_KIND_DB, C_DB_CREATE, &lg);
     if (lr) return lr;
-    void *p = calloc(1, len ? len : 1);
+    void *p = db_alloc(len);
     if (!p) return OCR_ENOMEM;
     Op *o = emit(C_DB_CREATE);
     o->a = lg ? lg : pool_take(OCRGPU_KIND_DB); o->b = (u64)(uintptr_t)p;
@@ -556,13 +570,13 @@ static void *pack_args(int argc, char **argv, u64 *len_out) {
     return p;
 }
 
-int ocrshim_run(int argc, char **argv) {
-    /* -ocr:cfg <file> is accepted and ignored: capacities come from the environment */
-    int uargc = 0; char **uargv = calloc((size_t)argc + 1, sizeof *uargv);
-    for (int i = 0; i < argc; ++i) {
-        if (!strncmp(argv[i], "-ocr:", 5)) { if (i + 1 < argc && strcmp(argv[i], "-ocr:version")) ++i; continue; }
-        uargv[uargc++] = argv[i];
-    }
+/* ---- bring-up, the worker loop, tear-down ----------------------------------------------------------------------
+ * One run queue for the whole process: ocrgpu_pop_ready fills it a level at a time, run_one() takes the next EDT.  A
+ * body that blocks (ocrLegacyBlockProgress) keeps calling run_one() from inside, so the EDTs popped with it still run. */
+static u64 *rq_p0, *rq_dg, *rq_dv; static u32 *rq_dc, *rq_df; static size_t rq_cap_e, rq_cap_d; static u64 rq_n, rq_pos;
+static u64 n_levels, n_bodies;
+
+static int shim_init(void) {
     g_verbose = (int)env_u64("OCRSHIM_VERBOSE", 0);
     ocrgpu_config_t cfg; memset(&cfg, 0, sizeof cfg);
     cfg.max_edt = (u32)env_u64("OCRSHIM_MAX_EDT", 1u << 20);
@@ -572,9 +586,120 @@ int ocrshim_run(int argc, char **argv) {
     cfg.max_edges = env_u64("OCRSHIM_MAX_EDGES", 1u << 23);
     cfg.location = 0;
     cfg.flags = env_u64("OCRSHIM_NANNY", 1) ? OCRGPU_F_NANNY : 0; /* user programs: report double satisfies (hc-task.c:1243) */
+    /* a second bring-up in one process (legacy blocks, ocr-legacy.h:74) starts from nothing */
+    ++init_epoch;
+    g_shutdown = g_exit_code = 0;
+    n_task = n_tpl = n_ops = 0; n_touched = 0; n_range = 0; rq_n = rq_pos = 0; n_levels = n_bodies = 0;
+    memset(pools, 0, sizeof pools);
+    if (dbmap_cap) { memset(dbmap, 0, dbmap_cap * sizeof *dbmap); dbmap_n = 0; }
+    if (labset_cap) { memset(labset, 0, labset_cap * sizeof *labset); memset(labalive, 0, labset_cap); labset_n = 0; }
     int rc = ocrgpu_init(&G, (int)env_u64("OCRSHIM_DEVICE", 0), &cfg);
     if (rc) { fprintf(stderr, "ocrshim: ocrgpu_init failed (%d): %s\n", rc, ocrgpu_last_error()); return 71; }
+    if (!rq_cap_e) {
+        rq_cap_e = 1024; rq_cap_d = 4096;
+        rq_p0 = xrealloc(NULL, 8 * rq_cap_e); rq_dg = xrealloc(NULL, 8 * rq_cap_d); rq_dv = xrealloc(NULL, 8 * rq_cap_d);
+        rq_dc = xrealloc(NULL, 4 * rq_cap_e); rq_df = xrealloc(NULL, 4 * rq_cap_e);
+    }
+    return 0;
+}
 
+/* deferred calls -> engine, one level, what became ready -> run queue.  0 = nothing left that could ever run */
+static int refill(void) {
+    for (;;) {
+        flush();
+        u64 has_ready = 0, pending = 0;
+        double tt = now_s();
+        CHK(ocrgpu_step(G, 1, 0, &has_ready, &pending, NULL));
+        t_step += now_s() - tt; tt = now_s();
+        ++n_levels;
+        u64 ne = 0, nd = 0;
+        for (;;) {
+            int rc = ocrgpu_pop_ready(G, rq_cap_e, rq_cap_d, &ne, &nd, rq_p0, rq_dc, rq_df, rq_dg, rq_dv);
+            if (rc == OCRGPU_ENOMEM && (ne > rq_cap_e || nd > rq_cap_d)) {
+                if (ne > rq_cap_e) { rq_cap_e = ne + ne / 2; rq_p0 = xrealloc(rq_p0, 8 * rq_cap_e); rq_dc = xrealloc(rq_dc, 4 * rq_cap_e); rq_df = xrealloc(rq_df, 4 * rq_cap_e); }
+                if (nd > rq_cap_d) { rq_cap_d = nd + nd / 2; rq_dg = xrealloc(rq_dg, 8 * rq_cap_d); rq_dv = xrealloc(rq_dv, 8 * rq_cap_d); }
+                continue;
+            }
+            if (rc) die("ocrgpu_pop_ready failed (%d): %s", rc, ocrgpu_last_error());
+            break;
+        }
+        t_pop += now_s() - tt;
+        rq_n = ne; rq_pos = 0;
+        if (ne) return 1;
+        if (!has_ready) return 0; /* else: built-in bodies only on this level */
+    }
+}
+
+/* taskExecute for the next ready EDT (hc-task.c:1864-2181).  0 = no EDT can run any more */
+static int run_one(void) {
+    if (rq_pos == rq_n && !refill()) return 0;
+    const u64 i = rq_pos++;
+    if (rq_p0[i] >= n_task) die("engine returned an unknown task handle");
+    const u64 ti = rq_p0[i];
+    /* the task array may move while the body creates EDTs: work on a copy */
+    Task t = tasks[ti];
+    if (t.destroyed) return 1;
+    tasks[ti].ran = 1;
+    if (rq_dc[i] != t.depc) die("depc mismatch for task %llu", (unsigned long long)ti);
+    /* depv is the body's own: a body that blocks runs other bodies underneath it */
+    ocrEdtDep_t small[16], *depv = t.depc <= 16 ? small : xrealloc(NULL, t.depc * sizeof *depv);
+    for (u32 k = 0; k < t.depc; ++k) {
+        depv[k].guid.guid = (intptr_t)rq_dg[rq_df[i] + k]; depv[k].ptr = (void *)(uintptr_t)rq_dv[rq_df[i] + k]; depv[k].mode = DB_DEFAULT_MODE;
+    }
+    double tt = now_s();
+    body_begin(&t);
+    ocrGuid_t ret = t.fn(t.paramc, t.paramv, t.depc, depv);
+    body_end(&t, (u64)ret.guid);
+    t_bodies += now_s() - tt;
+    free(tasks[ti].paramv); tasks[ti].paramv = NULL;
+    if (depv != small) free(depv);
+    ++n_bodies;
+    return 1;
+}
+
+static int shim_fini(void) {
+    ocrgpu_stats_t st; memset(&st, 0, sizeof st);
+    CHK(ocrgpu_get_stats(G, &st));
+    u64 errs = 0; for (int i = 0; i < 8; ++i) errs += st.err[i];
+    if (g_verbose || errs)
+        fprintf(stderr, "ocrshim: levels=%llu bodies=%llu edt_sat=%llu evt_sat=%llu err=[%llu %llu %llu %llu %llu %llu %llu]\n",
+                (unsigned long long)n_levels, (unsigned long long)n_bodies, (unsigned long long)st.edt_sat, (unsigned long long)st.evt_sat,
+                (unsigned long long)st.err[0], (unsigned long long)st.err[1], (unsigned long long)st.err[2], (unsigned long long)st.err[3],
+                (unsigned long long)st.err[4], (unsigned long long)st.err[5], (unsigned long long)st.err[6]);
+    if (g_verbose)
+        fprintf(stderr, "ocrshim: seconds: bodies %.3f | queue sort %.3f | batched C-ABI calls %.3f | ocrgpu_step %.3f | ocrgpu_pop_ready %.3f\n",
+                t_bodies, t_sort, t_calls, t_step, t_pop);
+    if (errs && !g_exit_code) g_exit_code = 73;
+    ocrgpu_fini(G); G = NULL;
+    return g_exit_code;
+}
+
+static void run_until_shutdown(void) {
+    while (!g_shutdown)
+        if (!run_one()) {
+            fprintf(stderr, "ocrshim: no runnable EDT left and ocrShutdown() was not called (%llu EDTs ran)\n", (unsigned long long)n_bodies);
+            g_exit_code = 72;
+            break;
+        }
+}
+
+static int strip_ocr_args(int argc, char **argv, char **uargv, const char **ini) {
+    int uargc = 0; /* -ocr:cfg <file> is accepted and ignored: capacities come from the environment */
+    for (int i = 0; i < argc; ++i) {
+        if (!strncmp(argv[i], "-ocr:", 5)) { if (i + 1 < argc && strcmp(argv[i], "-ocr:version")) { ++i; if (ini) *ini = argv[i]; } continue; }
+        uargv[uargc++] = argv[i];
+    }
+    return uargc;
+}
+
+/* a legacy-mode program has its own main() and no mainEdt */
+extern ocrGuid_t mainEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) __attribute__((weak));
+
+int ocrshim_run(int argc, char **argv) {
+    if (!mainEdt) { fprintf(stderr, "ocrshim: the program defines neither mainEdt nor main\n"); return 70; }
+    char **uargv = calloc((size_t)argc + 1, sizeof *uargv);
+    int uargc = strip_ocr_args(argc, argv, uargv, NULL);
+    int rc = shim_init(); if (rc) return rc;
     /* mainEdt(paramc 0, depc 1: the argument datablock), ocr-driver.c:1034-1060 */
     u64 alen; void *args = pack_args(uargc, uargv, &alen);
     body_begin(NULL);
@@ -584,70 +709,81 @@ int ocrshim_run(int argc, char **argv) {
     ocrEdtDep_t mdep = { adb, aptr, DB_MODE_RW };
     mainEdt(0, NULL, 1, &mdep);
     body_end(NULL, 0);
+    run_until_shutdown();
+    return shim_fini();
+}
 
-    size_t cap_e = 1024, cap_d = 4096;
-    u64 *p0 = xrealloc(NULL, 8 * cap_e), *dg = xrealloc(NULL, 8 * cap_d), *dv = xrealloc(NULL, 8 * cap_d);
-    u32 *dc = xrealloc(NULL, 4 * cap_e), *df = xrealloc(NULL, 4 * cap_e);
-    ocrEdtDep_t *depv = NULL; size_t cap_depv = 0;
-    u64 levels = 0, bodies = 0;
-    while (!g_shutdown) {
-        flush();
-        u64 has_ready = 0, pending = 0;
-        double tt = now_s();
-        CHK(ocrgpu_step(G, 1, 0, &has_ready, &pending, NULL));
-        t_step += now_s() - tt; tt = now_s();
-        ++levels;
-        u64 ne = 0, nd = 0;
-        for (;;) {
-            rc = ocrgpu_pop_ready(G, cap_e, cap_d, &ne, &nd, p0, dc, df, dg, dv);
-            if (rc == OCRGPU_ENOMEM && (ne > cap_e || nd > cap_d)) {
-                if (ne > cap_e) { cap_e = ne + ne / 2; p0 = xrealloc(p0, 8 * cap_e); dc = xrealloc(dc, 4 * cap_e); df = xrealloc(df, 4 * cap_e); }
-                if (nd > cap_d) { cap_d = nd + nd / 2; dg = xrealloc(dg, 8 * cap_d); dv = xrealloc(dv, 8 * cap_d); }
-                continue;
-            }
-            if (rc) die("ocrgpu_pop_ready failed (%d): %s", rc, ocrgpu_last_error());
-            break;
-        }
-        t_pop += now_s() - tt; tt = now_s();
-        if (ne == 0) {
-            if (has_ready) continue; /* built-in bodies only on this level */
-            fprintf(stderr, "ocrshim: no runnable EDT left and ocrShutdown() was not called (%llu EDTs ran)\n", (unsigned long long)bodies);
-            g_exit_code = 72;
-            break;
-        }
-        for (u64 i = 0; i < ne && !g_shutdown; ++i) {
-            if (p0[i] >= n_task) die("engine returned an unknown task handle");
-            /* the task array may move while the body creates EDTs: work on a copy */
-            Task t = tasks[p0[i]];
-            if (t.destroyed) continue;
-            tasks[p0[i]].ran = 1;
-            if (dc[i] != t.depc) die("depc mismatch for task %llu", (unsigned long long)p0[i]);
-            if (t.depc > cap_depv) { cap_depv = t.depc + 16; depv = xrealloc(depv, cap_depv * sizeof *depv); }
-            for (u32 k = 0; k < t.depc; ++k) {
-                depv[k].guid.guid = (intptr_t)dg[df[i] + k]; depv[k].ptr = (void *)(uintptr_t)dv[df[i] + k]; depv[k].mode = DB_DEFAULT_MODE;
-            }
-            body_begin(&t);
-            ocrGuid_t ret = t.fn(t.paramc, t.paramv, t.depc, depv);
-            body_end(&t, (u64)ret.guid);
-            free(tasks[p0[i]].paramv); tasks[p0[i]].paramv = NULL;
-            ++bodies;
-        }
-        t_bodies += now_s() - tt;
-    }
-    ocrgpu_stats_t st; memset(&st, 0, sizeof st);
-    CHK(ocrgpu_get_stats(G, &st));
-    u64 errs = 0; for (int i = 0; i < 8; ++i) errs += st.err[i];
-    if (g_verbose || errs)
-        fprintf(stderr, "ocrshim: levels=%llu bodies=%llu edt_sat=%llu evt_sat=%llu err=[%llu %llu %llu %llu %llu %llu %llu]\n",
-                (unsigned long long)levels, (unsigned long long)bodies, (unsigned long long)st.edt_sat, (unsigned long long)st.evt_sat,
-                (unsigned long long)st.err[0], (unsigned long long)st.err[1], (unsigned long long)st.err[2], (unsigned long long)st.err[3],
-                (unsigned long long)st.err[4], (unsigned long long)st.err[5], (unsigned long long)st.err[6]);
-    if (g_verbose)
-        fprintf(stderr, "ocrshim: seconds: bodies %.3f | queue sort %.3f | batched C-ABI calls %.3f | ocrgpu_step %.3f | ocrgpu_pop_ready %.3f\n",
-                t_bodies, t_sort, t_calls, t_step, t_pop);
-    if (errs && !g_exit_code) g_exit_code = 73;
-    ocrgpu_fini(G);
-    return g_exit_code;
+/* ---- legacy mode (ocr/inc/extensions/ocr-legacy.h, ocr/src/api/extensions/ocr-legacy.c): the program keeps its own
+ *      main(), brings the runtime up, starts EDTs from outside any EDT and waits for their results ---------------- */
+#include "extensions/ocr-legacy.h"
+void ocrParseArgs(int argc, const char *argv[], ocrConfig_t *cfg) {
+    if (!cfg) return;
+    cfg->userArgv = calloc((size_t)argc + 1, sizeof *cfg->userArgv); cfg->iniFile = NULL;
+    cfg->userArgc = strip_ocr_args(argc, (char **)argv, cfg->userArgv, &cfg->iniFile);
+}
+void ocrLegacyInit(ocrGuid_t *legacyContext, ocrConfig_t *cfg) {
+    (void)cfg;
+    int rc = shim_init(); if (rc) exit(rc);
+    body_begin(NULL); /* calls made from main() are queued like mainEdt's */
+    if (legacyContext) legacyContext->guid = 1;
+}
+u8 ocrLegacyFinalize(ocrGuid_t legacyContext, bool runUntilShutdown) {
+    (void)legacyContext;
+    body_end(NULL, 0);
+    if (runUntilShutdown) run_until_shutdown(); /* ocr-legacy.c:60-77 */
+    return (u8)shim_fini();
+}
+u8 ocrLegacySpawnOCR(ocrGuid_t *handle, ocrGuid_t finishEdtTemplate, u64 paramc, u64 *paramv, u64 depc, ocrGuid_t *depv, ocrGuid_t legacyContext) {
+    (void)legacyContext;
+    if (!handle || depc < 1 || !depv) return OCR_EINVAL; /* ocr-legacy.c:96: the first dependence holds the EDT back */
+    ocrGuid_t sticky, edt, out, depv0 = depv[0];
+    ocrEventCreate(&sticky, OCR_EVENT_STICKY_T, EVT_PROP_TAKES_ARG);
+    depv[0] = UNINITIALIZED_GUID;
+    u8 r = ocrEdtCreate(&edt, finishEdtTemplate, (u32)paramc, paramv, (u32)depc, depv, EDT_PROP_FINISH, NULL_HINT, &out);
+    depv[0] = depv0;
+    if (r) return r;
+    ocrAddDependence(out, sticky, 0, DB_DEFAULT_MODE);
+    ocrAddDependence(depv0, edt, 0, DB_DEFAULT_MODE);
+    *handle = sticky;
+    return 0;
+}
+/* the EDT the blocked caller waits behind: it takes what the event carried and wakes the caller */
+typedef struct { int done; ocrGuid_t guid; void *ptr; } Watch;
+static ocrGuid_t watchEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) {
+    (void)paramc; (void)depc;
+    Watch *w = (Watch *)(uintptr_t)paramv[0];
+    w->guid = depv[0].guid; w->ptr = depv[0].ptr; w->done = 1;
+    return NULL_GUID;
+}
+u8 ocrLegacyBlockProgress(ocrGuid_t evtHandle, ocrGuid_t *guid, void **result, u64 *size, u16 properties) {
+    (void)properties;
+    const u64 g = (u64)evtHandle.guid;
+    if (g == 0 || g >= (u64)-2 || !(OCRGPU_GUID_KIND(g) & OCRGPU_KIND_EVENT)) return OCR_EINVAL;
+    static ocrGuid_t tpl; static int have_tpl; static u64 tpl_epoch;
+    if (!have_tpl || tpl_epoch != init_epoch) { ocrEdtTemplateCreate(&tpl, watchEdt, 1, 1); have_tpl = 1; tpl_epoch = init_epoch; }
+    Watch w = { 0, NULL_GUID_INITIALIZER, NULL };
+    u64 pv = (u64)(uintptr_t)&w;
+    /* the watcher is no child of the caller's finish scope: it must not hold that scope open, nor be counted in it */
+    const u64 scope = cur_scope; cur_scope = 0;
+    ocrGuid_t we; ocrEdtCreate(&we, tpl, 1, &pv, 1, &evtHandle, EDT_PROP_NONE, NULL_HINT, NULL);
+    cur_scope = scope;
+    /* what the caller has issued so far takes effect now (its children check in before they can check out); the
+     * caller's own context comes back when the wait is over */
+    Task *t = cur_task; /* lives in the caller's run_one() frame (NULL: main) */
+    ocrGuid_t els_keep[OCRSHIM_ELS_SLOTS]; memcpy(els_keep, els_slots, sizeof els_keep);
+    body_pause();
+    while (!w.done && !g_shutdown)
+        if (!run_one()) { fprintf(stderr, "ocrshim: ocrLegacyBlockProgress: nothing left to run and the event was not satisfied\n"); g_exit_code = 72; g_shutdown = 1; }
+    body_begin(t); /* everything issued before the wait has been flushed: program order starts over */
+    memcpy(els_slots, els_keep, sizeof els_keep);
+    if (guid) *guid = w.guid;
+    if (result) *result = w.ptr;
+    if (size) *size = db_len(w.ptr);
+    return w.done ? 0 : OCR_ECANCELED;
+}
+ocrGuid_t ocrWait(ocrGuid_t outputEvent) { /* ocr-legacy.c:115-123 */
+    ocrGuid_t out;
+    return ocrLegacyBlockProgress(outputEvent, &out, NULL, NULL, LEGACY_PROP_NONE) == 0 ? out : (ocrGuid_t)ERROR_GUID_INITIALIZER;
 }
 
 /* libocr provides main() and calls the program's mainEdt (ocr-driver.c:1000-1060); so does the shim */

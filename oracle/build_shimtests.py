@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = "/root/reference/ocr"
 TESTS = os.path.join(REF, "tests", "non-regression-tests")
-DIRS = ["events", "finish", "edt", "datablock", "guidlabel", "dist", "lifecycle", "rtapi"]
+DIRS = ["events", "finish", "edt", "datablock", "guidlabel", "dist", "lifecycle", "rtapi", "legacy"]
 ARGS = {"testGuidLabelFib": ["12"]}          # command-line arguments a program needs
 # programs whose console lines depend on which of two concurrent EDTs wins a labeled create: only exit code and
 # PASSED/FAILURE lines are compared
@@ -30,7 +30,7 @@ OUT_REF = os.path.join(HERE, "_ref", "reftests")
 OUT_SHIM = os.path.join(HERE, "_ref", "shimtests")
 FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_programs.json")
 APP_DEFS = ["-DENABLE_EXTENSION_PARAMS_EVT", "-DENABLE_EXTENSION_COUNTED_EVT", "-DENABLE_EXTENSION_CHANNEL_EVT",
-            "-DENABLE_EXTENSION_RTITF", "-DENABLE_EXTENSION_LABELING", "-DENABLE_EXTENSION_AFFINITY", "-DOCR_ASSERT"]
+            "-DENABLE_EXTENSION_RTITF", "-DENABLE_EXTENSION_LEGACY", "-DENABLE_EXTENSION_LABELING", "-DENABLE_EXTENSION_AFFINITY", "-DOCR_ASSERT"]
 
 
 def args_of(src, name):
@@ -56,7 +56,7 @@ def build_ref(src, out):
 
 def build_shim(src, out):
     cmd = ["gcc", "-O1", "-w", "-std=gnu11", "-DENABLE_EXTENSION_PARAMS_EVT", "-DENABLE_EXTENSION_COUNTED_EVT",
-           "-DENABLE_EXTENSION_LABELING", "-DENABLE_EXTENSION_AFFINITY", "-DENABLE_EXTENSION_CHANNEL_EVT", "-DENABLE_EXTENSION_RTITF", "-I", os.path.join(ROOT, "include", "ocr_shim"), "-I", os.path.join(ROOT, "include"),
+           "-DENABLE_EXTENSION_LABELING", "-DENABLE_EXTENSION_AFFINITY", "-DENABLE_EXTENSION_CHANNEL_EVT", "-DENABLE_EXTENSION_RTITF", "-DENABLE_EXTENSION_LEGACY", "-I", os.path.join(ROOT, "include", "ocr_shim"), "-I", os.path.join(ROOT, "include"),
            src, os.path.join(ROOT, "ocr_amd", "libocrshim.a"), "-L", os.path.join(ROOT, "ocr_amd"), "-locrgpu",
            "-Wl,-rpath,$ORIGIN/../../../ocr_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", out]
     return subprocess.run(cmd, capture_output=True, text=True).returncode == 0
