@@ -604,7 +604,9 @@ static int shim_init(void) {
 }
 
 /* deferred calls -> engine, one level, what became ready -> run queue.  0 = nothing left that could ever run */
+static double t_refilled;   /* when the run queue was last filled: the time until the next refill went into bodies */
 static int refill(void) {
+    if (t_refilled != 0.0) t_bodies += now_s() - t_refilled;
     for (;;) {
         flush();
         u64 has_ready = 0, pending = 0;
@@ -625,6 +627,7 @@ static int refill(void) {
         }
         t_pop += now_s() - tt;
         rq_n = ne; rq_pos = 0;
+        t_refilled = now_s();
         if (ne) return 1;
         if (!has_ready) return 0; /* else: built-in bodies only on this level */
     }
@@ -646,11 +649,9 @@ static int run_one(void) {
     for (u32 k = 0; k < t.depc; ++k) {
         depv[k].guid.guid = (intptr_t)rq_dg[rq_df[i] + k]; depv[k].ptr = (void *)(uintptr_t)rq_dv[rq_df[i] + k]; depv[k].mode = DB_DEFAULT_MODE;
     }
-    double tt = now_s();
     body_begin(&t);
     ocrGuid_t ret = t.fn(t.paramc, t.paramv, t.depc, depv);
     body_end(&t, (u64)ret.guid);
-    t_bodies += now_s() - tt;
     free(tasks[ti].paramv); tasks[ti].paramv = NULL;
     if (depv != small) free(depv);
     ++n_bodies;
