@@ -46,20 +46,16 @@ def main():
     torch.cuda.set_device(local)
     backend = os.environ.get("OCRGPU_BENCH_BACKEND", "nccl")
     if world > 1:
+        # The default group is a gloo one (it always comes up); the exchange runs on an RCCL group created next to it,
+        # and only after that group has passed a self-test on every rank -- otherwise the job stays on gloo with
+        # host-staged records and says so in config.workload.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local),   # eager: the RCCL communicator is built here
-                                    timeout=datetime.timedelta(seconds=300))
-        else:
-            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
 
     from ocr_amd import engine, opstream
     if world > 1:
         if backend == "nccl":
             backend = collectives_selftest(torch, dist, local)
-        elif os.environ.get("OCRGPU_BENCH_HOST_GROUP"):      # rehearsal of the fallback plumbing
-            from ocr_amd import distributed as D
-            D.HOST_GROUP = dist.new_group(backend="gloo")
         return main_partitioned(args, torch, dist, rank, world, local, backend)
 
     # ---- build: every rank owns one partition = one independent layered DAG (seeded per rank) ----
@@ -152,35 +148,44 @@ def main():
 
 
 def collectives_selftest(torch, dist, local):
-    """The three collectives the exchange uses (count all-to-all, ragged uint8 all-to-all-v with empty splits, int64
-    all-gather) on RCCL, checked for content.  If RCCL refuses one of them the job falls back to a gloo group with
-    host-staged records (ocr_amd.distributed.HOST_GROUP) -- slower, still the same protocol -- and says so in
-    config.workload."""
+    """Create the RCCL group and run the collectives the exchange uses on it (count all-to-all, ragged uint8
+    all-to-all-v with empty splits, equal-split all-to-all, int64 all-gather), checked for content.  The verdict is
+    agreed over the gloo default group: RCCL is used only if EVERY rank passed (ocr_amd.distributed.DEV_GROUP)."""
     import sys
+    from ocr_amd import distributed as D
     W, r = dist.get_world_size(), dist.get_rank()
     dev = torch.device("cuda", local)
+    ok, why, g = 1, "", None
     try:
+        g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
         out_counts = [(r + d) % 3 for d in range(W)]
         cnt_out = torch.tensor(out_counts, dtype=torch.int64, device=dev)
         cnt_in = torch.empty_like(cnt_out)
-        dist.all_to_all_single(cnt_in, cnt_out)
+        dist.all_to_all_single(cnt_in, cnt_out, group=g)
         cin = [int(x) for x in cnt_in.cpu().tolist()]
         assert cin == [(s + r) % 3 for s in range(W)], cin
         send = torch.full((sum(out_counts), 32), r, dtype=torch.uint8, device=dev)
         recv = torch.empty((sum(cin), 32), dtype=torch.uint8, device=dev)
-        dist.all_to_all_single(recv, send, output_split_sizes=cin, input_split_sizes=out_counts)
+        dist.all_to_all_single(recv, send, output_split_sizes=cin, input_split_sizes=out_counts, group=g)
         want = torch.cat([torch.full((cin[s], 32), s, dtype=torch.uint8) for s in range(W)]) if sum(cin) else recv.cpu()
         assert torch.equal(recv.cpu(), want)
+        eq_s = torch.full((W, 3, 32), r, dtype=torch.uint8, device=dev)
+        eq_r = torch.empty_like(eq_s)
+        dist.all_to_all_single(eq_r.view(-1), eq_s.view(-1), group=g)
+        assert [int(eq_r[s, 0, 0]) for s in range(W)] == list(range(W))
         rows = [torch.empty_like(cnt_out) for _ in range(W)]
-        dist.all_gather(rows, cnt_out)
+        dist.all_gather(rows, cnt_out, group=g)
         assert [int(x[0]) for x in rows] == [s % 3 for s in range(W)]
         torch.cuda.synchronize()
+    except Exception as ex:  # noqa: BLE001 -- whatever RCCL refuses
+        ok, why = 0, f"{type(ex).__name__}: {str(ex)[:300]}"
+    verdict = torch.tensor([ok], dtype=torch.int64)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)          # gloo: every rank learns whether all of them passed
+    if int(verdict.item()) == 1:
+        D.DEV_GROUP = g
         return "nccl"
-    except Exception as ex:  # noqa: BLE001 -- any RCCL refusal lands here on every rank
-        print(f"[bench] rank {r}: RCCL collectives self-test failed ({type(ex).__name__}: {ex}); falling back to gloo", file=sys.stderr)
-        from ocr_amd import distributed as D
-        D.HOST_GROUP = dist.new_group(backend="gloo")   # every rank takes this branch: the failure is not rank-specific
-        return "gloo"
+    print(f"[bench] rank {r}: RCCL group unusable ({why or 'another rank failed'}); the exchange stays on gloo", file=sys.stderr)
+    return "gloo"
 
 
 def main_partitioned(args, torch, dist, rank, world, local, backend):
@@ -190,13 +195,10 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     from ocr_amd import engine
     from ocr_amd.distributed import resolve_distributed, distributed_exchange
     from ocr_amd.workloads import LayeredPartition
-    cdev = "cpu" if backend == "gloo" else torch.device("cuda", local)
-
-    from ocr_amd import distributed as D
-    grp = D.HOST_GROUP                           # None unless the RCCL self-test failed
+    grp = None                                   # control collectives below: tiny tensors on the default (gloo) group
 
     def allreduce_sum(x):
-        t = torch.tensor([int(x)], dtype=torch.int64, device=cdev)
+        t = torch.tensor([int(x)], dtype=torch.int64)
         dist.all_reduce(t, group=grp)
         return int(t.item())
 
@@ -228,7 +230,7 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
         levels = step()
     fence()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=grp)
     dt = float(t.item())
     st = part.eng.stats()

@@ -317,9 +317,16 @@ def resolve_lockstep(parts):
 
 
 HOST_GROUP = None   # set to a gloo group to route every collective of the exchange through host memory
+DEV_GROUP = None    # set to an RCCL ("nccl") group to keep the exchange on the GPUs when the default group is a gloo one
+
+
+def _grp():
+    return DEV_GROUP if DEV_GROUP is not None else HOST_GROUP
 
 
 def _host(dist):
+    if DEV_GROUP is not None:
+        return False
     return HOST_GROUP is not None or dist.get_backend() == "gloo"
 
 
@@ -331,7 +338,7 @@ def exchange_records(dist, send, counts, device):
     cdev = "cpu" if _host(dist) else device
     cnt_out = torch.as_tensor(np.asarray(counts, dtype=np.int64)).to(cdev)
     cnt_in = torch.empty_like(cnt_out)
-    dist.all_to_all_single(cnt_in, cnt_out, group=HOST_GROUP)
+    dist.all_to_all_single(cnt_in, cnt_out, group=_grp())
     cin = cnt_in.cpu().numpy()
     return exchange_payload(dist, send, counts, cin, device), int(cin.sum())
 
@@ -346,7 +353,7 @@ def exchange_payload(dist, send, counts_out, counts_in, device):
     sendbuf = (torch.cat(pieces) if pieces else send[0, :0]).contiguous().to(cdev)
     recv = torch.empty((int(np.sum(counts_in)), REC_BYTES), dtype=torch.uint8, device=cdev)
     dist.all_to_all_single(recv, sendbuf, output_split_sizes=[int(x) for x in counts_in],
-                           input_split_sizes=[int(x) for x in counts_out], group=HOST_GROUP)
+                           input_split_sizes=[int(x) for x in counts_out], group=_grp())
     return recv.to(device)
 
 
@@ -357,7 +364,7 @@ def _dist_round(part, dist, fire):
     ready, _, counts = part.eng.step(1 if fire else 0, force_level=bool(fire), want_counts=True)
     vec = torch.tensor([int(c) for c in counts] + [int(ready)], dtype=torch.int64, device=cdev)
     rows = [torch.empty_like(vec) for _ in range(W)]
-    dist.all_gather(rows, vec, group=HOST_GROUP)
+    dist.all_gather(rows, vec, group=_grp())
     return torch.stack(rows).cpu().numpy()
 
 
@@ -412,7 +419,7 @@ def _resolve_one_collective_per_level(part, dist):
         hdr[:, 0] = torch.from_numpy(counts.astype(np.int64))
         hdr[:, 1] = part.eng.step_info()[0] + int(counts.sum())
         part.send[:, C, :] = hdr.view(torch.uint8).to(dev)
-        dist.all_to_all_single(recv.view(-1), (part.send.cpu() if host else part.send).view(-1), group=HOST_GROUP)
+        dist.all_to_all_single(recv.view(-1), (part.send.cpu() if host else part.send).view(-1), group=_grp())
         h = recv[:, C, :].cpu().contiguous().view(torch.int64).numpy()
         part.eng.exchange_reset()
         cin = h[:, 0].astype(np.uint32)
