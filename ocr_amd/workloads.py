@@ -63,7 +63,9 @@ class LayeredPartition:
         # mean + slack (they are Poisson-like: sd ~ sqrt(mean)); the start event's fan-out is width/W per destination.
         # One more slot per region for the header of the one-collective-per-level exchange.
         per_pair = self.n_edges_global // max(N // width - 1, 1) // (W * W)    # from global figures: every rank must get the same cap
-        cap = (max(2 * per_pair, width // W + 1024) + 4096 + 1) if W > 1 else 16
+        # records one rank sends another per level: binomial around per_pair (10 sigma + 1024 of room); the last layer's
+        # EDTs all DECR the sink latch, width/W records from every rank to the latch's owner
+        cap = (max(per_pair + 10 * int(per_pair ** 0.5) + 1024, width // W + 1024) + 1) if W > 1 else 16
         self.send_cap = cap
         # no event of this DAG that a remote satisfy can reach has a remote waiter (the latch and the sink EDT both
         # live on rank 0; the start event is satisfied by rank 0 itself before the first level)
