@@ -412,24 +412,40 @@ def _resolve_one_collective_per_level(part, dist):
     hdr = torch.zeros((W, 4), dtype=torch.int64)
     recv = torch.empty(part.send.shape, dtype=torch.uint8, device="cpu" if host else dev)
     levels = 0
+    import os
+    import time
+    timing = bool(os.environ.get("OCRGPU_DIST_TIMING"))      # where a level's wall time goes (rank 0 prints it)
+    tm = [0.0] * 5
     while True:
+        t0 = time.perf_counter()
         _, _, counts = part.eng.step(1, force_level=True, want_counts=True)
+        t1 = time.perf_counter()
         if int(counts.max()) > C:
             raise RuntimeError(f"send region overflow: {int(counts.max())} records for one partition, room for {C}")
         hdr[:, 0] = torch.from_numpy(counts.astype(np.int64))
         hdr[:, 1] = part.eng.step_info()[0] + int(counts.sum())
         part.send[:, C, :] = hdr.view(torch.uint8).to(dev)
+        t2 = time.perf_counter()
         dist.all_to_all_single(recv.view(-1), (part.send.cpu() if host else part.send).view(-1), group=_grp())
+        t3 = time.perf_counter()
         h = recv[:, C, :].cpu().contiguous().view(torch.int64).numpy()
+        t4 = time.perf_counter()
         part.eng.exchange_reset()
         cin = h[:, 0].astype(np.uint32)
         if cin.any():
             rdev = recv.to(dev) if host else recv
             part.eng.exchange_apply_strided(rdev.data_ptr(), W, C + 1, cin)
+        if timing:
+            t5 = time.perf_counter()
+            for k, dt in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                tm[k] += dt
         if h[:, 1].sum() == 0:
             break
         levels += 1
     part.eng.step(0, drop_empty_level=True)
+    if timing and rank == 0 and levels:
+        print("[dist timing] us per level: step %.1f | header %.1f | all-to-all %.1f | header read %.1f | reset+apply %.1f" %
+              tuple(1e6 * x / (levels + 1) for x in tm), flush=True)
     return levels
 
 
