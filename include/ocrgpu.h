@@ -173,6 +173,12 @@ int ocrgpu_resolve(ocrgpu_engine_t *e, uint64_t max_levels, ocrgpu_stats_t *stat
 /* before anything else: if the last level recorded is a forced one in which nothing fired, forget it (a lockstep
  * driver that learns only afterwards that every partition was idle uses this to undo its final probe level) */
 #define OCRGPU_STEP_DROP_EMPTY_LEVEL 2u
+/* OCRGPU_STEP_WRITE_HEADERS: when the step is over, write into the LAST record slot of every destination region of the
+ * send buffer the 32-byte header {u64 records queued for that destination, u64 this partition's activity in the step
+ * (ready-log entries fired + records sent), 0, 0}: an equal-split all-to-all of the whole buffer then tells every
+ * receiver how many records to apply and whether anybody is still working -- one collective per level, no host
+ * round trip to build the header.  The caller keeps records_per_dest - 1 slots for records. */
+#define OCRGPU_STEP_WRITE_HEADERS 4u
 int ocrgpu_step(ocrgpu_engine_t *e, uint32_t fire_levels, uint32_t flags, uint64_t *has_ready_out,
                 uint64_t *pending_records_out, uint32_t *send_counts_out /* host [n_locations] or NULL */);
 

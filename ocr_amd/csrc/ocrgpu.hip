@@ -1136,6 +1136,17 @@ __global__ void k_exchange_apply_strided(Dev d, u32 n_src, u64 stride, u32 max_c
     if (s >= n_src || k >= cnt[s]) return;
     apply_record(d, recs[(u64)s * stride + k], proxy_base + cnt[n_src + s] + k);
 }
+// OCRGPU_STEP_WRITE_HEADERS: {records for this destination, my activity} in the last record slot of every region
+__global__ void k_exchange_headers(Dev d, u32 K) {
+    const u32 loc = threadIdx.x;
+    if (loc >= d.n_loc) return;
+    const State *S = &d.ctrl->state[K & 1];
+    u64 sent = 0;
+    for (u32 l = 0; l < d.n_loc; ++l) { u32 c = d.send_cnt[l * 32]; sent += c > d.send_cap ? d.send_cap : c; }
+    u32 mine = d.send_cnt[loc * 32]; if (mine > d.send_cap) mine = d.send_cap;
+    u64 *h = (u64 *)&d.send[(size_t)loc * d.send_cap + (d.send_cap - 1)];
+    h[0] = mine; h[1] = (u64)(S->r_end - S->r_begin) + sent; h[2] = 0; h[3] = 0;
+}
 __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
 __global__ void k_exchange_counts(Dev d, u32 *out) { if (threadIdx.x < d.n_loc) { u32 c = d.send_cnt[threadIdx.x * 32]; out[threadIdx.x] = c > d.send_cap ? d.send_cap : c; } }
 
@@ -1305,7 +1316,7 @@ struct ocrgpu_engine {
     Snapshot snap;
     hipEvent_t ev0, ev1; bool have_events; u32 step_grid; u32 launch_index; u64 fired_cap; bool defer_drain; u32 *send_cnt_dev;
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
-    u32 *pinned_done;
+    u32 *pinned_done; u32 apply_flip; hipEvent_t apply_ev[2];
     u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
 };
 
@@ -1406,6 +1417,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->have_events = false;
+    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr;
     e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->pop_cursor = e->snap_pop_cursor = 0; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
     { const char *mp = getenv("OCRGPU_SPREAD_WGS"); u32 v = mp ? (u32)atoi(mp) : 256u; d.spread_wgs = v < 1 ? 1u : (v > MAX_GRID ? (u32)MAX_GRID : v); }
@@ -1459,7 +1471,8 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     // ctrl.level starts at -1 (main-program satisfies are "level -1")
     Ctrl h; memset(&h, 0, sizeof h); h.level = 0xFFFFFFFFu; h.state[0].done = h.state[1].done = 1;
     if (hipMemcpyAsync(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice, e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "ctrl init failed"); }
-    if (hipHostMalloc((void **)&e->pinned_done, 256 + 128 * 1024) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
+    // u32 index: [0,32) the polled State; [32, 32 + 32*1024) send counters of up to 1024 locations; [33000, 34000) small read-backs
+    if (hipHostMalloc((void **)&e->pinned_done, 4 * 34816) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
     if (cfg->flags & OCRGPU_F_TIMING) { if (hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess) e->have_events = true; }
     if (hipStreamSynchronize(e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "init sync failed"); }
 #undef TRY
@@ -1504,6 +1517,7 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     if (e->scan_partials) (void)hipFree(e->scan_partials);
     if (e->snap.valid) snap_free(e->snap);
     if (e->pinned_done) (void)hipHostFree(e->pinned_done);
+    for (int i = 0; i < 2; ++i) if (e->apply_ev[i]) (void)hipEventDestroy(e->apply_ev[i]);
     if (e->have_events) { (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1); }
     delete e;
     return 0;
@@ -1796,6 +1810,11 @@ extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *
     // 3 launches cover the common single-level case (FIRE, the no-op that notices quiescence, one spare)
     int r = run_steps(e, fire_levels, ~0ull, true, flags & (OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_DROP_EMPTY_LEVEL), fire_levels == 1 ? 3u : 2u);
     if (r) return r;
+    if (flags & OCRGPU_STEP_WRITE_HEADERS) {
+        if (!e->d.send_cnt || e->d.n_loc > 1024 || e->d.send_cap < 2) FAIL(OCRGPU_EINVAL, "exchange not configured");
+        k_exchange_headers<<<1, 1024, 0, e->stream>>>(e->d, e->launch_index);
+        HIPCHK(hipGetLastError());
+    }
     const State *S = (const State *)e->pinned_done; // the poll that saw `done` brought the final state and counters
     if (has_ready_out) *has_ready_out = S->r_total > S->r_end ? 1 : 0;
     if (pending_records_out) *pending_records_out = S->q_total > S->q_end ? S->q_total - S->q_end : 0;
@@ -1896,11 +1915,26 @@ extern "C" int ocrgpu_exchange_apply_strided(ocrgpu_engine_t *e, const void *rec
     if (total == 0) return 0;
     if ((u64)e->n_db + total > e->cfg.max_db) FAIL(OCRGPU_ENOMEM, "max_db=%u exhausted by proxy datablocks", e->cfg.max_db);
     int r = stage_reserve(e, rup(8 * (size_t)n_src)); if (r) return r;
-    const u32 *dc; if ((r = stage_in(e, cp.data(), 2 * (u64)n_src, OCRGPU_HOST, &dc))) return r;
+    // the counts go through pinned memory that outlives this call (two alternating halves, each guarded by an event), so the
+    // copy can stay asynchronous
+    if (n_src > 200) { // beyond the pinned scratch: stage from the vector and wait
+        const u32 *dc; if ((r = stage_in(e, cp.data(), 2 * (u64)n_src, OCRGPU_HOST, &dc))) return r;
+        k_exchange_apply_strided<<<nblk((u64)n_src * mx), 256, 0, e->stream>>>(e->d, n_src, stride_records, mx, dc, (const SendRec *)recs_dev, e->n_db);
+        e->n_db += (u32)total;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(e->stream));
+        return 0;
+    }
+    const u32 half = (e->apply_flip ^= 1u);
+    u32 *pin = e->pinned_done + 33100 + 400 * half;
+    if (!e->apply_ev[half]) HIPCHK(hipEventCreateWithFlags(&e->apply_ev[half], hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(e->apply_ev[half])); // the copy out of this half two calls ago (long done in practice)
+    memcpy(pin, cp.data(), 8 * (size_t)n_src);
+    const u32 *dc; if ((r = stage_in(e, pin, 2 * (u64)n_src, OCRGPU_HOST, &dc))) return r;
+    HIPCHK(hipEventRecord(e->apply_ev[half], e->stream));
     k_exchange_apply_strided<<<nblk((u64)n_src * mx), 256, 0, e->stream>>>(e->d, n_src, stride_records, mx, dc, (const SendRec *)recs_dev, e->n_db);
     e->n_db += (u32)total;
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(e->stream)); // `cp` was staged from the stack
     return 0;
 }
 extern "C" int ocrgpu_exchange_apply(ocrgpu_engine_t *e, const void *recs, u64 n, int where) {

@@ -409,7 +409,6 @@ def _resolve_one_collective_per_level(part, dist):
     dev = part.send.device
     C = part.send.shape[1] - 1                      # record slots per region; slot C holds the header
     distributed_exchange(part, dist)                # main-time satisfies (the start event's fan-out) settle the general way
-    hdr = torch.zeros((W, 4), dtype=torch.int64)
     recv = torch.empty(part.send.shape, dtype=torch.uint8, device="cpu" if host else dev)
     levels = 0
     import os
@@ -418,14 +417,11 @@ def _resolve_one_collective_per_level(part, dist):
     tm = [0.0] * 5
     while True:
         t0 = time.perf_counter()
-        _, _, counts = part.eng.step(1, force_level=True, want_counts=True)
+        _, _, counts = part.eng.step(1, force_level=True, want_counts=True, write_headers=True)  # the engine fills slot C
         t1 = time.perf_counter()
         if int(counts.max()) > C:
             raise RuntimeError(f"send region overflow: {int(counts.max())} records for one partition, room for {C}")
-        hdr[:, 0] = torch.from_numpy(counts.astype(np.int64))
-        hdr[:, 1] = part.eng.step_info()[0] + int(counts.sum())
-        part.send[:, C, :] = hdr.view(torch.uint8).to(dev)
-        t2 = time.perf_counter()
+        t2 = t1
         dist.all_to_all_single(recv.view(-1), (part.send.cpu() if host else part.send).view(-1), group=_grp())
         t3 = time.perf_counter()
         h = recv[:, C, :].cpu().contiguous().view(torch.int64).numpy()

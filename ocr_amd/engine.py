@@ -228,13 +228,13 @@ class Engine:
         self._chk(self.lib.ocrgpu_resolve(self.h, C.c_uint64(max_levels), C.byref(st)))
         return st
 
-    def step(self, fire_levels=1, force_level=False, want_counts=False, drop_empty_level=False):
+    def step(self, fire_levels=1, force_level=False, want_counts=False, drop_empty_level=False, write_headers=False):
         """Close pending satisfies, fire at most ``fire_levels`` levels, close again.  Returns
         (has_ready, pending_records[, send_counts]) -- all from the one synchronisation the run ends with."""
         hr, pr = C.c_uint64(), C.c_uint64()
         counts = np.zeros(self.n_locations, np.uint32) if want_counts else None
         self._chk(self.lib.ocrgpu_step(self.h, C.c_uint32(fire_levels),
-                                       C.c_uint32((1 if force_level else 0) | (2 if drop_empty_level else 0)),
+                                       C.c_uint32((1 if force_level else 0) | (2 if drop_empty_level else 0) | (4 if write_headers else 0)),
                                        C.byref(hr), C.byref(pr), _ptr(counts)))
         if want_counts:
             return bool(hr.value), int(pr.value), counts
