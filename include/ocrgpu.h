@@ -79,6 +79,14 @@ typedef struct {
  * list is dealt over, default 256), OCRGPU_STEP_GRID (grid of a step launch, default 2048). */
 #define OCRGPU_F_NANNY 1u  /* detect double satisfy of an EDT pre-slot (hc-task.c:1243); +1 atomic per edge */
 #define OCRGPU_F_TIMING 2u /* bracket resolve's kernels with HIP events on the engine stream   */
+#define OCRGPU_F_LOCKABLE_DB 8u /* the cfg's datablockfactory=Lockable instead of Regular: an EDT whose pre-slots are all
+                                 * satisfied first acquires its datablocks, in ascending guid order, each once, in the mode
+                                 * its ocrAddDependence named (DB_MODE_CONST / RW / EW / RO), waits in line on a busy one
+                                 * and only then becomes ready; the level that fires it releases them (iterateDbFrontier
+                                 * hc-task.c:484-544, lockableAcquireInternal / lockableRelease
+                                 * lockable-datablock.c:139-263, 330-507).  One partition only (no exchange).  Which of
+                                 * several contenders gets a datablock first is a race, as it is between the reference's
+                                 * workers; everything but the levels of the contenders is deterministic.             */
 
 typedef struct {
     uint64_t levels;        /* topological levels run by the last resolve                      */
@@ -160,6 +168,10 @@ int ocrgpu_event_satisfy_slot(ocrgpu_engine_t *e, uint64_t n, const uint64_t *ev
                               const uint32_t *slot, int where);
 /* ocrEventDestroy (ocr-edt.c:101) */
 int ocrgpu_event_destroy(ocrgpu_engine_t *e, uint64_t n, const uint64_t *evt, int where);
+/* OCRGPU_F_LOCKABLE_DB with host-run bodies (OCRBODY_HOST): the EDTs named have run -- release every datablock they
+ * acquired (taskEpilogue's release loop, hc-task.c:1723-1751 -> lockableRelease lockable-datablock.c:330); EDTs the
+ * datablocks are handed to become ready in the next ocrgpu_step / ocrgpu_resolve.  Built-in bodies release by themselves. */
+int ocrgpu_edt_release_dbs(ocrgpu_engine_t *e, uint64_t n, const uint64_t *edt, int where);
 
 /* ---- the worker loop (replaces SCHED_NOTIFY(EDT_READY) -> deque push -> SCHED_GET_WORK ->
  *      taskExecute -> taskEpilogue, common-scheduler.c:234-313, hc-scheduler-heuristic.c:148-333,

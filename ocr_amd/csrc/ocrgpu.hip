@@ -45,10 +45,12 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_
 #define RF_PIECE 32u    // record only: fan out piece `slot` (BIG_ROW edges) of the fired event's row
 #define RF_CHANGEN 128u // record only (with RF_FIRED): a CHANNEL pairing; `slot` = index in waiters[] of the waiter that takes `payload`
 #define RF_LAZYWALK 64u // record only: pre-slot `slot` of frontier-tracked EDT `dst` was satisfied -> lazy_walk()
+#define RF_ACQUIRE 256u // record only (Lockable datablocks): EDT `dst` goes on acquiring its datablocks -> acq_walk()
 #define INLINE_SLOTS 6u
 #define SLOT_MARK 0x80000000u  // pre-slot word: the slot has been satisfied
 #define PEND_LAZY 0x40000000u  // EdtLine.pending: a COUNTED event sits on a pre-slot the frontier has not reached -> track the frontier
-#define PEND_MASK 0x3FFFFFFFu
+#define PEND_ACQ 0x20000000u   // EdtLine.pending: Lockable datablocks -- the EDT acquires its datablocks before it is scheduled
+#define PEND_MASK 0x1FFFFFFFu
 #define LAZY_FRONT 0xFFFFFFFFu // lazy_tab key slot of an EDT's frontier word
 #define CNT_SAT (1ull << 63)   // counted[]: [satisfied:1 | registrations left:31 | lazy registrations not yet made:32]
 #define BODY_F_SCRIPT 0x10000u // internal: EDT has a script
@@ -75,6 +77,12 @@ struct Rec { u32 dst, payload, slot, flags; };      // one pending satisfy: dst 
 // in chan_sat[].  counted[x] = [satisfies so far:32 | registrations so far:32], one atomic per op.
 struct ChanRec { u32 cap, wait_base, sat_base, pad; };
 struct Script { u32 target, payload, slot, op_kind; }; // op | payload_kind<<8
+// Lockable datablock (lockable-datablock.h): state = modeLock << 30 | numUsers; heads of the three LIFO waiter lists
+// (EDT index + 1; the link to the next waiter sits in the upper half of the waiting EDT's `val`)
+struct DbLock { u32 state, ew, itw, ro; };
+#define DBL_EW 1u
+#define DBL_ITW 2u
+#define DBL_USERS 0x3FFFFFFFu
 // A satisfy whose destination lives on another partition (GPU): what crosses xGMI instead of the reference's
 // marshalled ocrPolicyMsg_t (hc-dist-policy.c:2208, mpi-comm-platform.c:1055).  The datablock travels by value
 // (16-byte DBs), the way hc-dist's ProxyDb_t clones it on acquire (hc-dist-policy.c:382-700).
@@ -124,6 +132,7 @@ struct Dev {
     u32 *log_src; u64 *log_rec; // registration log the CSR is built from
     // datablocks (explicit [0,max_db) then the output DB of EDT e at max_db+e): {value, tag}
     ulonglong2 *db;
+    DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB only: lock word + waiter lists per datablock; access mode per EDT pre-slot
     // work lists
     u32 *fired;                 // fired/ready log, grouped by level
     u32 *level_start;           // level_start[L] = offset in `fired`
@@ -227,9 +236,16 @@ __device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, const Step &S, u3
         *sp = word | SLOT_MARK;
     }
     const u32 old = atomicSub(&L->pending, 1u);
-    if (old & PEND_LAZY) { // rare: this EDT's frontier is tracked (COUNTED accounting); the walk runs in the next EVENTS phase
-        const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
-        if (qi < d.q_cap) d.q[qi] = Rec{edt, 0u, slot, RF_LAZYWALK}; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+    if (old & (PEND_LAZY | PEND_ACQ)) { // rare
+        if (old & PEND_LAZY) { // this EDT's frontier is tracked (COUNTED accounting); the walk runs in the next EVENTS phase
+            const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
+            if (qi < d.q_cap) d.q[qi] = Rec{edt, 0u, slot, RF_LAZYWALK}; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+        }
+        if ((old & PEND_ACQ) && (old & PEND_MASK) == 1u) { // Lockable datablocks: all satisfied -> acquire first (taskAllDepvSatisfied)
+            const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
+            if (qi < d.q_cap) d.q[qi] = Rec{edt, 0u, 0u, RF_ACQUIRE}; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+            return false;
+        }
     }
     return (old & PEND_MASK) == 1u;
 }
@@ -322,6 +338,87 @@ __device__ __forceinline__ void lazy_walk(const Dev &d, u32 edt, u32 slot) {
             if (xv) lazy_reached(d, *xv);
         }
         f = atomicAdd((unsigned long long *)F, 0ull);
+    }
+}
+
+// ---- Lockable datablocks: acquire modes on the ready path -----------------------------------
+// An EDT whose pre-slots are all satisfied acquires its datablocks one by one in ascending order, each once, in the mode
+// its ocrAddDependence named (taskAllDepvSatisfied / iterateDbFrontier, hc-task.c:662-705, 484-544), queues on the first
+// busy one (lockableAcquireInternal, lockable-datablock.c:139-263) and becomes ready when it holds them all; the level
+// that fires it releases them and the last user hands the datablock on (lockableRelease :330-507).
+// No lock is needed around a datablock's record because the two sides never run in the same launch: acquisitions and
+// enqueues happen in EVENTS launches (state only gets busier: a "busy" verdict read there stays true until the launch
+// ends), releases and hand-overs in FIRE launches and in k_release_dbs (the last user owns the record outright).
+__device__ __forceinline__ size_t acq_index(const Dev &d, u32 edt, u32 depc, u32 ovf_base, u32 slot) {
+    return depc <= INLINE_SLOTS ? (size_t)edt * INLINE_SLOTS + slot : (size_t)d.max_edt * INLINE_SLOTS + ovf_base + slot;
+}
+// true = acquired; false = OCR_EBUSY: queued on the list of its mode (push-front like the reference's lists)
+__device__ __forceinline__ bool db_acquire(const Dev &d, u32 db, u32 mode, u32 e) {
+    DbLock *B = &d.dbl[db];
+    u32 o = atomicAdd(&B->state, 0u);
+    for (;;) {
+        const u32 lock = o >> 30;
+        u32 nw = o + 1u, *list = nullptr;                                                        // RO: falls through (:171)
+        if (mode == OCRMODE_CONST) { if (lock) list = &B->ro; }                                   // :173-190
+        else if (mode == OCRMODE_EW) { if (o) list = &B->ew; else nw = (DBL_EW << 30) | 1u; }      // :192-212
+        else if (mode == OCRMODE_RW) {                                                            // :214-249 (one location)
+            if (lock == DBL_ITW) { }
+            else if (o) list = &B->itw;
+            else nw = (DBL_ITW << 30) | 1u;
+        }
+        if (list) { reinterpret_cast<u32 *>(&d.edt[e].val)[1] = atomicExch(list, e + 1u); return false; }
+        const u32 prev = atomicCAS(&B->state, o, nw);
+        if (prev == o) return true;
+        o = prev;
+    }
+}
+// iterateDbFrontier: go on from the last datablock taken (lower half of `val`); true = holds them all -> scheduleTask
+__device__ __forceinline__ bool acq_walk(const Dev &d, u32 e) {
+    EdtLine *L = &d.edt[e];
+    const u32 depc = L->depc;
+    const u32 *sl = depc <= INLINE_SLOTS ? L->slot : d.slots + L->slot[0];
+    const unsigned char *md = d.acq_mode + acq_index(d, e, depc, L->slot[0], 0u);
+    u32 last = (u32)L->val;
+    for (;;) {
+        u32 best = 0xFFFFFFFFu, bm = 0; // the next datablock in ascending order; named twice = the mode of its lowest pre-slot (stable sort :459-477)
+        for (u32 k = 0; k < depc; ++k) { const u32 p = sl[k] & 0x7FFFFFFFu; if (p > last && p < best) { best = p; bm = md[k]; } }
+        if (best == 0xFFFFFFFFu) { L->val = 0; return true; }
+        last = best;
+        reinterpret_cast<u32 *>(&L->val)[0] = last; // moved on before the attempt, like frontierSlot (:491)
+        if (!db_acquire(d, best - 1u, bm, e)) return false;
+    }
+}
+// lockableRelease: `push(edt)` queues an RF_ACQUIRE record for every waiter the datablock is handed to
+template <class Push>
+__device__ __forceinline__ void db_release(const Dev &d, u32 db, Push push) {
+    DbLock *B = &d.dbl[db];
+    const u32 o = atomicSub(&B->state, 1u);
+    if ((o & DBL_USERS) == 0u) { atomicAdd(&B->state, 1u); atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; } // released more often than acquired
+    if ((o & DBL_USERS) != 1u) return;
+    // last user (:364-486): nobody else touches this record until the launch ends
+    u32 w = 0, n = 0, lock = 0;
+    if (o >> 30) w = atomicExch(&B->ro, 0u);                     // the writer(s) left: every reader in line (:375-382, 459-476)
+    if (!w) {
+        w = atomicExch(&B->itw, 0u);                             // every RW waiter of the location (:390-438)
+        if (w) lock = DBL_ITW;
+        else if ((w = atomicAdd(&B->ew, 0u)) != 0u) {            // one EW waiter (:393-395, 439-458)
+            atomicExch(&B->ew, reinterpret_cast<u32 *>(&d.edt[w - 1u].val)[1]);
+            push(w - 1u);
+            atomicExch(&B->state, (DBL_EW << 30) | 1u);
+            return;
+        }
+    }
+    for (; w; w = reinterpret_cast<u32 *>(&d.edt[w - 1u].val)[1]) { ++n; push(w - 1u); }
+    atomicExch(&B->state, (lock << 30) | n);
+}
+template <class Push>
+__device__ __forceinline__ void release_all(const Dev &d, const u32 *sl, u32 depc, Push push) { // the epilogue's release loop
+    for (u32 k = 0; k < depc; ++k) {
+        const u32 p = sl[k] & 0x7FFFFFFFu;
+        if (!p) continue;
+        bool dup = false;
+        for (u32 j = 0; j < k; ++j) dup |= (sl[j] & 0x7FFFFFFFu) == p;
+        if (!dup) db_release(d, p - 1u, push);
     }
 }
 
@@ -657,6 +754,11 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                         }
                     }
                 }
+                if (d.dbl && depc && !host_body) // Lockable datablocks: the body has run, its datablocks go back (host bodies: ocrgpu_edt_release_dbs)
+                    release_all(d, sl, depc, [&](u32 w) {
+                        const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
+                        if (qi < d.q_cap) d.q[qi] = Rec{w, 0u, 0u, RF_ACQUIRE}; else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
+                    });
                 if ((body & OCRBODY_F_OUTEVT) && !host_body) { // epilogue: satisfy the ONCE output event with the returned guid
                     ++n_evt_sat;
                     bool ok = true;
@@ -689,6 +791,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (act) {
                 r = d.q[i];
                 if (r.flags & RF_LAZYWALK) lazy_walk(d, r.dst, r.slot);
+                else if (r.flags & RF_ACQUIRE) ready = acq_walk(d, r.dst);
                 else if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, S, r.dst, r.slot, r.payload, r.flags); ++n_edt_sat; }
                 else if (!(r.flags & RF_FIRED)) { kind = (*evt_state(d, r.dst) >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
             }
@@ -697,7 +800,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             bool fire = latch_group(d, is_latch, r.dst, r.slot);
             if (act && (r.flags & RF_CHANGEN)) { deg = 1; sg.row = r.slot; sg.payload = r.payload; } // a CHANNEL pairing made in a fan-out
             else if (act && (r.flags & RF_FIRED)) fire = true;
-            else if (act && !(r.flags & (RF_DST_EDT | RF_LAZYWALK)) && !is_latch) {
+            else if (act && !(r.flags & (RF_DST_EDT | RF_LAZYWALK | RF_ACQUIRE)) && !is_latch) {
                 if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM || kind == OCREVT_COUNTED) fire = evt_satisfy_simple(d, r.dst, kind, r.payload);
                 else if (kind == OCREVT_CHANNEL && (*evt_state(d, r.dst) & 0xFF) == ST_LIVE) {
                     u32 wp; if (chan_satisfy(d, r.dst, r.payload, wp)) { deg = 1; sg.row = wp; sg.payload = r.payload; } // the waiter in line takes it now
@@ -827,7 +930,7 @@ __global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, con
     if (i >= n) return;
     u32 e = first_idx + (u32)i, dc = depc[i], b = body[i] & 0xFFFFu;
     EdtLine L;
-    L.pending = dc; L.depc = dc; L.body = b;
+    L.pending = dc | ((d.dbl && dc) ? PEND_ACQ : 0u); L.depc = dc; L.body = b;
     L.param0 = param0 ? param0[i] : (u64)e; L.val = 0;
     L.out_row = 0; L.out_deg = 0;
     L.out_state = (b & OCRBODY_F_OUTEVT) ? (ST_LIVE | (OCREVT_ONCE << 8)) : (u32)ST_ABSENT; // ONCE output event (hc-task.c:940-959)
@@ -941,6 +1044,8 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
     if (!resolve_dst(d, dg, slot[i], didx, dflag, dslot)) { bad_op(d); return; }
     const bool d_edt = (dflag & RF_DST_EDT) != 0;
     u32 mnull = (d_edt && mode[i] == OCRMODE_NULL) ? RF_MODE_NULL : 0u;
+    if (d.acq_mode && d_edt && s != OCRGPU_NULL_GUID) // registerSignalerTaskHc records the mode (hc-task.c:1373); a NULL source does not
+        d.acq_mode[acq_index(d, didx, (dflag & RF_INLINE) ? 0u : INLINE_SLOTS + 1u, d.edt[didx].slot[0], dslot)] = (unsigned char)mode[i];
     if (s == OCRGPU_NULL_GUID) { q_push(d, Rec{didx, 0u, dslot, dflag}); return; } // == satisfy(dst, slot, NULL)
     u64 sv = gtab_get(d, s);
     u32 sk = OCRGPU_GUID_KIND(s);
@@ -1297,8 +1402,10 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); return OCRGPU_EHIP; } } while (0)
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
-struct Snapshot { EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; u64 *chan_wait; u32 *chan_sat; u32 chan_wait_used, chan_sat_used; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries; bool valid; };
+struct Snapshot { DbLock *dbl; EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; u64 *chan_wait; u32 *chan_sat; u32 chan_wait_used, chan_sat_used; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries; bool valid; };
 static void snap_free(Snapshot &s) {
+    if (s.dbl) (void)hipFree(s.dbl);
+    s.dbl = nullptr;
     (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.counted); (void)hipFree(s.lazy_tab); (void)hipFree(s.slots); (void)hipFree(s.chan_wait); (void)hipFree(s.chan_sat); (void)hipFree(s.fired); (void)hipFree(s.ctrl);
     s.valid = false;
 }
@@ -1416,7 +1523,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->device = device; e->stream = 0; e->cfg = *cfg;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
-    e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->have_events = false;
+    e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->snap.dbl = nullptr; e->have_events = false;
     e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr;
     e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->pop_cursor = e->snap_pop_cursor = 0; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
@@ -1425,7 +1532,9 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     d.max_slots = cfg->max_slots ? cfg->max_slots : 1; d.max_edges = cfg->max_edges ? cfg->max_edges : 1;
     d.max_levels = cfg->max_levels ? cfg->max_levels : (1u << 20);
     u64 n_evt_total = (u64)cfg->max_evt + cfg->max_edt, n_db_total = (u64)cfg->max_db + cfg->max_edt;
-    u64 q_cap = 2 * (n_evt_total + cfg->max_edt) + 4096; if (q_cap > 0xFFFFFFF0ull) q_cap = 0xFFFFFFF0ull;
+    u64 q_cap = 2 * (n_evt_total + cfg->max_edt) + 4096;
+    if (cfg->flags & OCRGPU_F_LOCKABLE_DB) q_cap += 2 * (u64)cfg->max_edt + d.max_slots + 6 * (u64)cfg->max_edt; // one record per EDT + one per hand-over
+    if (q_cap > 0xFFFFFFF0ull) q_cap = 0xFFFFFFF0ull;
     d.q_cap = (u32)q_cap; e->q_cap = (u32)q_cap;
     u64 objs = n_evt_total + n_db_total + cfg->max_edt;
     u64 gs = cfg->guid_slots ? cfg->guid_slots : 2 * objs;
@@ -1453,6 +1562,10 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.log_src, 4 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.log_rec, 8 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.db, 16 * (size_t)n_db_total));
+    if (cfg->flags & OCRGPU_F_LOCKABLE_DB) {
+        TRY(dalloc(e, (void **)&d.dbl, sizeof(DbLock) * (size_t)n_db_total));
+        TRY(dalloc(e, (void **)&d.acq_mode, (size_t)cfg->max_edt * INLINE_SLOTS + (size_t)d.max_slots));
+    }
     u64 fired_cap = (u64)cfg->max_edt + d.max_edges + 4096; if (fired_cap > 0xFFFFFFF0ull) fired_cap = 0xFFFFFFF0ull;
     e->fired_cap = fired_cap; d.fired_cap = (u32)fired_cap;
     TRY(dalloc(e, (void **)&d.fired, 4 * (size_t)fired_cap, false));
@@ -1780,6 +1893,29 @@ extern "C" int ocrgpu_event_destroy(ocrgpu_engine_t *e, u64 n, const u64 *evt, i
     return 0;
 }
 
+// Host-run bodies (OCRBODY_HOST) under OCRGPU_F_LOCKABLE_DB: the EDTs named have run; what they hold is released.
+__global__ void k_release_dbs(Dev d, u64 n, const u64 *edt) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 v = gtab_get(d, edt[i]);
+    if (!v || OCRGPU_GUID_KIND(edt[i]) != OCRGPU_KIND_EDT) { bad_op(d); return; }
+    const EdtLine *L = &d.edt[(u32)(v - 1)];
+    const u32 depc = L->depc;
+    release_all(d, depc <= INLINE_SLOTS ? L->slot : d.slots + L->slot[0], depc, [&](u32 w) { q_push(d, Rec{w, 0u, 0u, RF_ACQUIRE}); });
+}
+extern "C" int ocrgpu_edt_release_dbs(ocrgpu_engine_t *e, u64 n, const u64 *edt, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!edt) FAIL(OCRGPU_EINVAL, "null array");
+    if (!e->d.dbl) FAIL(OCRGPU_EINVAL, "engine was not created with OCRGPU_F_LOCKABLE_DB");
+    int r = stage_reserve(e, rup(8 * n)); if (r) return r;
+    const u64 *de; if ((r = stage_in(e, edt, n, where, &de))) return r;
+    k_release_dbs<<<nblk(n), 256, 0, e->stream>>>(e->d, n, de);
+    HIPCHK(hipGetLastError());
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 // ---- worker loop ----------------------------------------------------------------------------------------------
 static int fetch_stats(ocrgpu_engine *e, ocrgpu_stats_t *out) {
     Ctrl h;
@@ -1875,6 +2011,7 @@ extern "C" int ocrgpu_step_info(ocrgpu_engine_t *e, u64 *out4) {
 //      ocr/src/inc/ocr-comm-platform.h:55-199; the transport itself -- RCCL all-to-all -- is the caller's) ----
 extern "C" int ocrgpu_exchange_config(ocrgpu_engine_t *e, u32 n_locations, void *send_dev_buf, u64 records_per_dest, u64 max_remote_dsts) {
     ENTER(e);
+    if (e->d.dbl) FAIL(OCRGPU_EINVAL, "OCRGPU_F_LOCKABLE_DB arbitrates within one partition: not with an exchange configured");
     if (n_locations == 0 || n_locations > 1024 || e->cfg.location >= n_locations) FAIL(OCRGPU_EINVAL, "bad n_locations");
     if (n_locations > 1 && (!send_dev_buf || records_per_dest == 0 || records_per_dest > 0xFFFFFFFFull)) FAIL(OCRGPU_EINVAL, "send buffer required");
     Dev &d = e->d;
@@ -1958,6 +2095,11 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     int r = seal(e); if (r) return r;
     Dev &d = e->d; Snapshot &s = e->snap;
     if (s.valid) { HIPCHK(hipStreamSynchronize(e->stream)); snap_free(s); }
+    s.dbl = nullptr;
+    if (d.dbl) {
+        HIPCHK(hipMalloc((void **)&s.dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt)));
+        HIPCHK(hipMemcpyAsync(s.dbl, d.dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt), hipMemcpyDeviceToDevice, e->stream));
+    }
     HIPCHK(hipMalloc((void **)&s.edt, sizeof(EdtLine) * (size_t)e->n_edt + 64));
     HIPCHK(hipMalloc((void **)&s.evt, sizeof(EvtRec) * (size_t)e->n_evt + 64));
     HIPCHK(hipMalloc((void **)&s.counted, 8 * (size_t)e->n_evt + 64));
@@ -1995,6 +2137,7 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     e->pop_cursor = e->snap_pop_cursor;
     e->n_db = s.n_db; // proxy datablocks cloned from other partitions since the snapshot are dropped
     if (e->d.send_cnt) k_exchange_reset<<<1, 1024, 0, e->stream>>>(e->d);
+    if (d.dbl && s.dbl) HIPCHK(hipMemcpyAsync(d.dbl, s.dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.edt, s.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.evt, s.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     if (e->n_evt) HIPCHK(hipMemcpyAsync(d.counted, s.counted, 8 * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));

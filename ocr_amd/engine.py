@@ -21,6 +21,7 @@ from .opstream import OpStream, Result
 HOST, DEVICE = 0, 1
 GUIDS_GIVEN = 4   # OR into `where` of the create calls: guid arrays are inputs (ocrgpu.h)
 F_NANNY, F_TIMING = 1, 2
+F_LOCKABLE_DB = 8  # datablocks arbitrate their acquire modes (the cfg's datablockfactory=Lockable)
 
 
 def LATCH_DELTA(k):
@@ -61,7 +62,7 @@ assert SCRIPT_OP_DT.itemsize == 24
 EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error", "ocrgpu_abi_version",
            "ocrgpu_guid_reserve", "ocrgpu_guid_put", "ocrgpu_guid_get", "ocrgpu_guid_remove",
            "ocrgpu_event_create", "ocrgpu_db_create", "ocrgpu_edt_create", "ocrgpu_edt_set_scripts",
-           "ocrgpu_set_hash_tag_base", "ocrgpu_add_dependence", "ocrgpu_event_satisfy_slot", "ocrgpu_event_destroy",
+           "ocrgpu_set_hash_tag_base", "ocrgpu_add_dependence", "ocrgpu_event_satisfy_slot", "ocrgpu_event_destroy", "ocrgpu_edt_release_dbs",
            "ocrgpu_resolve", "ocrgpu_step", "ocrgpu_step_info", "ocrgpu_pop_ready", "ocrgpu_exchange_apply_strided", "ocrgpu_exchange_config", "ocrgpu_exchange_counts",
            "ocrgpu_exchange_reset", "ocrgpu_exchange_apply", "ocrgpu_snapshot", "ocrgpu_restore", "ocrgpu_sync", "ocrgpu_read_edts",
            "ocrgpu_read_events", "ocrgpu_read_dbs", "ocrgpu_read_fired", "ocrgpu_get_stats"]
@@ -221,6 +222,11 @@ class Engine:
     def event_destroy(self, evt):
         evt = np.ascontiguousarray(evt, np.uint64)
         self._chk(self.lib.ocrgpu_event_destroy(self.h, C.c_uint64(len(evt)), _ptr(evt), HOST))
+
+    def edt_release_dbs(self, edt):
+        """F_LOCKABLE_DB, host-run bodies: the EDTs named have run; release the datablocks they hold."""
+        edt = np.ascontiguousarray(edt, np.uint64)
+        self._chk(self.lib.ocrgpu_edt_release_dbs(self.h, C.c_uint64(len(edt)), _ptr(edt), HOST))
 
     # ---- worker loop ----
     def resolve(self, max_levels=0):

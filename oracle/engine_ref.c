@@ -31,6 +31,15 @@
  *          event src -> waiter registration on the source event.
  *   Epilogue: script satisfies (the body's own ocrEventSatisfySlot calls) happen before the
  *          output event is satisfied with the returned guid (taskEpilogue hc-task.c:1822-1831).
+ *   Lockable datablocks (ocrref_run2 flag OCRREF_F_LOCKABLE = the cfg's datablockfactory=Lockable): an EDT whose
+ *          pre-slots are all satisfied acquires its datablocks one by one in ascending guid order, duplicates once,
+ *          in the mode its ocrAddDependence named (taskAllDepvSatisfied / iterateDbFrontier hc-task.c:662-705,
+ *          484-544; stable sort :459-477), queues on the first busy one (lockableAcquireInternal
+ *          lockable-datablock.c:139-263) and is scheduled once it holds them all; it releases them when its body has
+ *          run, and the last user hands the datablock on (lockableRelease :330-507).  Level-synchronous reading:
+ *          releases belong to the level that fires, acquisitions to the satisfies between two levels.  WHO wins a
+ *          contended datablock is a scheduling accident in the reference; this file serves contenders in the order
+ *          they got there, so `level` is one valid outcome (tests compare it through invariants, everything else exactly).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -45,10 +54,14 @@ typedef struct { uint32_t dst, slot; uint8_t dst_is_evt, mode_null; } waiter_t;
 /* CHANNEL: w[w_head..n_w) = registered waiters not yet paired, sq[sq_head..sq_n) = satisfies not yet paired (FIFO both) */
 typedef struct { uint32_t kind, state; int32_t counter; uint32_t data; uint32_t n_w, cap_w; waiter_t *w;
                  uint32_t w_head, sq_head, sq_n, sq_cap, *sq; } event_t;
-typedef struct { uint32_t depc, cnt, frontier; uint64_t slot_base; uint8_t created; } edtst_t;
+typedef struct { uint32_t depc, cnt, frontier; uint64_t slot_base; uint8_t created;
+                 uint32_t *order, acq_pos, acq_next; } edtst_t; /* Lockable: pre-slots in acquisition order, position, link in a waiter list */
+/* lockable-datablock.h: attributes.modeLock / numUsers + the three LIFO waiter lists (heads: EDT index + 1) */
+typedef struct { uint32_t lock, users, ew, itw, ro; } dblock_t;
+enum { DBL_NONE = 0, DBL_EW = 1, DBL_ITW = 2 };
 /* lazy_evt: a persistent event (index+1) named by ocrAddDependence on which the EDT has NOT registered yet: it does
  * so only when its frontier -- the first pre-slot not yet satisfied -- reaches this slot (hc-task.c:1286-1338,1361-1410) */
-typedef struct { uint32_t payload, lazy_evt; uint8_t sat, mode_null; } slot_t;
+typedef struct { uint32_t payload, lazy_evt; uint8_t sat, mode_null, mode; } slot_t;
 typedef struct { uint32_t idx, slot, payload; uint8_t is_evt, mode_null; } work_t;
 
 typedef struct {
@@ -58,6 +71,7 @@ typedef struct {
     uint32_t *ready_next; size_t n_next, cap_next;
     uint64_t *db_val; uint8_t *db_live;
     uint64_t err[N_ERR], n_edge_sat, n_evt_sat;
+    int lockable; dblock_t *dbl; uint32_t *acq; size_t n_acq, cap_acq; /* acq: EDTs whose datablock frontier is to be (re)started */
 } eng_t;
 
 static void push_work(eng_t *E, work_t w) {
@@ -67,6 +81,10 @@ static void push_work(eng_t *E, work_t w) {
 static void push_ready(eng_t *E, uint32_t e) {
     if (E->n_next == E->cap_next) { E->cap_next = E->cap_next ? 2 * E->cap_next : 1024; E->ready_next = realloc(E->ready_next, E->cap_next * 4); }
     E->ready_next[E->n_next++] = e;
+}
+static void push_acq(eng_t *E, uint32_t e) {
+    if (E->n_acq == E->cap_acq) { E->cap_acq = E->cap_acq ? 2 * E->cap_acq : 1024; E->acq = realloc(E->acq, E->cap_acq * 4); }
+    E->acq[E->n_acq++] = e;
 }
 static uint32_t ev_index(const eng_t *E, uint64_t r) {
     return OCRREF_CLS(r) == OCRREF_EVT ? (uint32_t)OCRREF_IDX(r) : E->h->n_evt + (uint32_t)OCRREF_IDX(r);
@@ -116,7 +134,7 @@ static void drain(eng_t *E) {
             if (s->sat) { E->err[ERR_DOUBLE_SLOT]++; continue; }
             s->sat = 1;
             s->payload = (w.mode_null || s->mode_null) ? 0 : w.payload;
-            if (++t->cnt == t->depc) { push_ready(E, w.idx); continue; }
+            if (++t->cnt == t->depc) { if (E->lockable) push_acq(E, w.idx); else push_ready(E, w.idx); continue; }
             if (w.slot == t->frontier) { /* advance the frontier over satisfied slots (hc-task.c:1288-1300) ... */
                 int cond = 1;
                 while (t->frontier != t->depc - 1 && cond) { t->frontier++; cond = E->slots[t->slot_base + t->frontier].sat; }
@@ -179,13 +197,14 @@ static void op_add_dep(eng_t *E, const ocrops_op_t *op) {
     if (sc == OCRREF_NULL || sc == OCRREF_DB || sc == OCRREF_OUTDB) {
         /* convertDepAddToSatisfy hc-policy.c:2857-2902; DB->EDT records the mode first */
         uint8_t mn = (sc == OCRREF_NULL) ? 0 : mode_null; /* NULL src: mode not recorded (signalers[].mode stays -1) */
+        if (!dst_is_evt && sc != OCRREF_NULL) E->slots[E->ed[dst].slot_base + op->slot].mode = op->mode;
         work_t w = { dst, op->slot, payload_of(E, op->a, 0, NULL), (uint8_t)dst_is_evt, mn };
         push_work(E, w); drain(E);
         return;
     }
     if (sc != OCRREF_EVT && sc != OCRREF_OUTEVT) { E->err[ERR_BAD_OP]++; return; }
     event_t *v = &E->ev[ev_index(E, op->a)];
-    if (!dst_is_evt) E->slots[E->ed[dst].slot_base + op->slot].mode_null = mode_null; /* registerSignalerTaskHc :1373 */
+    if (!dst_is_evt) { slot_t *ds = &E->slots[E->ed[dst].slot_base + op->slot]; ds->mode_null = mode_null; ds->mode = op->mode; } /* registerSignalerTaskHc :1373 */
     if (!dst_is_evt && (v->kind == OCREVT_STICKY || v->kind == OCREVT_IDEM || v->kind == OCREVT_COUNTED)) {
         /* persistent source, EDT destination: register now only on the frontier slot, else when the frontier gets
          * there (registerSignalerTaskHc :1391-1405) */
@@ -233,6 +252,65 @@ static void op_evt_destroy(eng_t *E, uint64_t r) {
     v->state = ST_DESTROYED;
 }
 
+/* ---- Lockable datablocks ------------------------------------------------------------------------------------ */
+/* lockableAcquireInternal (lockable-datablock.c:139-263): 0 = acquired, 1 = OCR_EBUSY (queued, LIFO like the reference's lists) */
+static int db_acquire(eng_t *E, uint32_t db, uint32_t mode, uint32_t e) {
+    dblock_t *L = &E->dbl[db];
+    uint32_t *list = NULL;
+    if (mode == OCRMODE_CONST) { if (L->lock) list = &L->ro; }                                    /* :173-190 */
+    else if (mode == OCRMODE_EW) { if (L->lock || L->users) list = &L->ew; else L->lock = DBL_EW; } /* :192-212 */
+    else if (mode == OCRMODE_RW) {                                                                 /* :214-249 */
+        if (L->lock == DBL_ITW) { /* one location: joins the writers */ }
+        else if (L->users || L->lock == DBL_EW) list = &L->itw;
+        else L->lock = DBL_ITW;
+    }                                                                                              /* RO: falls through (:171) */
+    if (list) { E->ed[e].acq_next = *list; *list = e + 1; return 1; }
+    L->users++;
+    return 0;
+}
+/* iterateDbFrontier (hc-task.c:484-544): go on acquiring from where the EDT stands; all held -> scheduleTask */
+static void acq_walk(eng_t *E, uint32_t e) {
+    edtst_t *t = &E->ed[e];
+    const slot_t *sl = &E->slots[t->slot_base];
+    if (!t->order && t->depc) { /* taskAllDepvSatisfied :662-693: ascending guid, stable (sortRegNode :459-477) */
+        t->order = malloc(4 * (size_t)t->depc);
+        for (uint32_t i = 0; i < t->depc; ++i) {
+            uint32_t j = i;
+            while (j > 0 && sl[t->order[j - 1]].payload > sl[i].payload) { t->order[j] = t->order[j - 1]; --j; }
+            t->order[j] = i;
+        }
+    }
+    while (t->acq_pos < t->depc) {
+        const uint32_t k = t->order[t->acq_pos++], p = sl[k].payload; /* pre-incremented like frontierSlot (:491) */
+        if (p == 0) continue;                                                   /* NULL_GUID (:492) */
+        if (t->acq_pos >= 2 && sl[t->order[t->acq_pos - 2]].payload == p) continue; /* duplicate: acquired once (:495-499) */
+        if (db_acquire(E, p - 1, sl[k].mode, e)) return;                        /* OCR_EBUSY: resumed by the release (:529-531) */
+    }
+    push_ready(E, e);
+}
+static void acq_drain(eng_t *E) {
+    for (size_t i = 0; i < E->n_acq; ++i) acq_walk(E, E->acq[i]); /* acq_walk appends nothing to acq */
+    E->n_acq = 0;
+}
+/* lockableRelease (lockable-datablock.c:330-507); a granted waiter goes on with its frontier (dependenceResolvedTaskHc) */
+static void db_release(eng_t *E, uint32_t db) {
+    dblock_t *L = &E->dbl[db];
+    if (L->users == 0) { E->err[ERR_BAD_OP]++; return; }
+    if (--L->users) return;
+    uint32_t w = 0;
+    if (L->lock) { L->lock = DBL_NONE; if (L->ro) { w = L->ro; L->ro = 0;       /* writer(s) gone: every reader in line (:375-382,459-476) */
+            for (; w; w = E->ed[w - 1].acq_next) { L->users++; push_acq(E, w - 1); } return; } }
+    if (L->itw) { L->lock = DBL_ITW; w = L->itw; L->itw = 0;                      /* every RW waiter of the location (:390-438) */
+        for (; w; w = E->ed[w - 1].acq_next) { L->users++; push_acq(E, w - 1); } }
+    else if (L->ew) { w = L->ew; L->ew = E->ed[w - 1].acq_next; L->lock = DBL_EW; L->users = 1; push_acq(E, w - 1); } /* one EW waiter (:393-395,439-458) */
+}
+static void release_all(eng_t *E, uint32_t e) { /* taskEpilogue's release loop over the acquired depv (hc-task.c:1723-1751) */
+    edtst_t *t = &E->ed[e];
+    const slot_t *sl = &E->slots[t->slot_base];
+    uint32_t prev = 0;
+    for (uint32_t i = 0; i < t->depc; ++i) { uint32_t p = sl[t->order[i]].payload; if (p && p != prev) db_release(E, p - 1); if (p) prev = p; }
+}
+
 /* taskExecute + taskEpilogue for one ready EDT (hc-task.c:1864-2181, 1707-1862) */
 static void fire(eng_t *E, uint32_t e, int32_t lvl, int32_t *level, uint64_t *val) {
     const ocrops_edt_t *d = &E->edt[e];
@@ -257,14 +335,25 @@ static void fire(eng_t *E, uint32_t e, int32_t lvl, int32_t *level, uint64_t *va
         else E->err[ERR_BAD_OP]++;
     }
     if (d->body & OCRBODY_F_OUTEVT) { work_t w = { E->h->n_evt + e, 0, ret, 1, 0 }; push_work(E, w); drain(E); }
+    if (E->lockable && d->depc) release_all(E, e);
 }
 
 /* Run a whole stream.  Outputs sized as in include/ocr_opstream.h; stats[16]:
  * [0] levels run, [1] EDTs fired, [2] EDT pre-slot satisfies, [3] event pre-slot satisfies, [8+i] error counters */
+#define OCRREF_F_LOCKABLE 1u
+int ocrref_run2(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_t *evt, const uint64_t *db_init,
+                const ocrops_op_t *main_ops, const ocrops_op_t *script,
+                int32_t *level, uint64_t *val, uint64_t *evt_state, uint64_t *db_val, uint64_t *stats, uint32_t flags);
 int ocrref_run(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_t *evt, const uint64_t *db_init,
                const ocrops_op_t *main_ops, const ocrops_op_t *script,
                int32_t *level, uint64_t *val, uint64_t *evt_state, uint64_t *db_val, uint64_t *stats) {
+    return ocrref_run2(h, edt, evt, db_init, main_ops, script, level, val, evt_state, db_val, stats, 0u);
+}
+int ocrref_run2(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_t *evt, const uint64_t *db_init,
+                const ocrops_op_t *main_ops, const ocrops_op_t *script,
+                int32_t *level, uint64_t *val, uint64_t *evt_state, uint64_t *db_val, uint64_t *stats, uint32_t flags) {
     eng_t E; memset(&E, 0, sizeof E);
+    E.lockable = (flags & OCRREF_F_LOCKABLE) != 0;
     E.h = h; E.edt = edt; E.evt = evt; E.script = script;
     uint32_t n_evt_total = h->n_evt + h->n_edt, n_db_total = h->n_db + h->n_edt;
     E.ev = calloc(n_evt_total + 1, sizeof(event_t));
@@ -274,6 +363,7 @@ int ocrref_run(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_
     E.slots = calloc(ns + 1, sizeof(slot_t));
     E.db_val = db_val; memset(db_val, 0, 8 * (size_t)n_db_total);
     E.db_live = calloc(n_db_total + 1, 1);
+    if (E.lockable) E.dbl = calloc(n_db_total + 1, sizeof(dblock_t));
     for (uint32_t x = 0; x < n_evt_total; ++x) E.ev[x].state = ST_ABSENT;
     memset(level, 0xFF, 4 * (size_t)h->n_edt); memset(val, 0, 8 * (size_t)h->n_edt);
 
@@ -285,12 +375,13 @@ int ocrref_run(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_
         case OCROP_DB_CREATE: E.db_val[op->a] = db_init[op->a]; E.db_live[op->a] = 1; break;
         case OCROP_EDT_CREATE: { uint32_t e = (uint32_t)op->a; E.ed[e].created = 1;
                                   if (edt[e].body & OCRBODY_F_OUTEVT) { event_t *v = &E.ev[h->n_evt + e]; v->kind = OCREVT_ONCE; v->state = ST_LIVE; }
-                                  if (edt[e].depc == 0) push_ready(&E, e); } break;
+                                  if (edt[e].depc == 0) push_ready(&E, e); } break; /* nothing to acquire */
         case OCROP_ADD_DEP: op_add_dep(&E, op); break;
         case OCROP_SATISFY: op_satisfy(&E, op, 0, NULL); break;
         case OCROP_EVT_DESTROY: op_evt_destroy(&E, op->a); break;
         default: E.err[ERR_BAD_OP]++; break;
         }
+        acq_drain(&E);
     }
     int32_t lvl = 0; uint64_t fired = 0;
     uint32_t *cur = NULL; size_t n_cur = 0;
@@ -298,6 +389,7 @@ int ocrref_run(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_
         free(cur); cur = E.ready_next; n_cur = E.n_next;
         E.ready_next = NULL; E.n_next = E.cap_next = 0;
         for (size_t i = 0; i < n_cur; ++i) fire(&E, cur[i], lvl, level, val);
+        acq_drain(&E); /* the level's releases are in: now the acquisitions they and its satisfies set off */
         fired += n_cur; ++lvl;
     }
     free(cur);
@@ -314,6 +406,8 @@ int ocrref_run(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt_
     }
     if (stats) { memset(stats, 0, 16 * 8); stats[0] = (uint64_t)lvl; stats[1] = fired; stats[2] = E.n_edge_sat; stats[3] = E.n_evt_sat;
                  for (int i = 0; i < N_ERR; ++i) stats[8 + i] = E.err[i]; }
+    for (uint32_t i = 0; i < h->n_edt; ++i) free(E.ed[i].order);
+    free(E.dbl); free(E.acq);
     free(E.ev); free(E.ed); free(E.slots); free(E.db_live); free(E.stack); free(E.ready_next);
     return 0;
 }

@@ -56,6 +56,10 @@ static struct {
     const char *res_path; int guid_is_map;
     struct timeval t0; int t0_set;
     uint64_t n_sat_edges;
+    /* OCR_REPLAY_LOCKABLE=1 (runs whose cfg names datablockfactory=Lockable): the Lamport clock also counts datablock
+     * hand-overs, and bodies watch for holders the arbitration should have kept apart */
+    int lockable; uint8_t *slot_mode; volatile long long *db_clk; /* [3*db]: last level of an EW / RW / CONST holder */
+    volatile uint64_t *db_busy; volatile uint32_t overlaps;
 } G;
 
 static double now_minus(struct timeval *a) {
@@ -115,6 +119,26 @@ static void do_satisfy(const ocrops_op_t *op, uint32_t self, long long lvl, ocrE
 
 static void dump_results(void);
 
+static void clk_max(volatile long long *p, long long v) {
+    long long o = *p;
+    while (o < v && !__sync_bool_compare_and_swap(p, o, v)) o = *p;
+}
+/* The datablocks EDT `id` holds while its body runs, as the reference acquired them (iterateDbFrontier hc-task.c:484-544):
+ * every non-NULL depv guid once, in the mode of its lowest pre-slot.  Returns how many; db[] / mode[] sized depc. */
+static uint32_t held_dbs(uint32_t id, u32 depc, ocrEdtDep_t depv[], uint32_t *db, uint32_t *mode) {
+    uint32_t n = 0;
+    for (u32 i = 0; i < depc; ++i) {
+        if (depv[i].ptr == NULL) continue;
+        uint32_t d = (uint32_t)((uint64_t *)depv[i].ptr)[1], seen = 0;
+        for (uint32_t k = 0; k < n; ++k) if (db[k] == d) seen = 1;
+        if (!seen) { db[n] = d; mode[n++] = G.slot_mode[G.slot_base[id] + i]; }
+    }
+    return n;
+}
+#define BUSY_EW (1ULL << 40)
+#define BUSY_RW (1ULL << 20)
+#define BUSY_CONST 1ULL
+
 static ocrGuid_t bodyEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) {
     uint32_t id = (uint32_t)paramv[0];
     const ocrops_edt_t *e = &G.edt[id];
@@ -134,6 +158,31 @@ static ocrGuid_t bodyEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) 
         if (depv[i].ptr != NULL) { pv = ((uint64_t *)depv[i].ptr)[0]; did = ((uint64_t *)depv[i].ptr)[1] + 1; }
         v = ocrops_hash_step(v, i, pv, did);
     }
+    uint32_t *hd = NULL, *hm = NULL, nh = 0;
+    if (G.lockable && depc) {
+        hd = malloc(8 * depc); hm = hd + depc;
+        nh = held_dbs(id, depc, depv, hd, hm);
+        for (uint32_t k = 0; k < nh; ++k) { /* who else is inside?  EW: nobody; RW: no EW, no CONST; CONST: no writer (RO is never kept out) */
+            volatile uint64_t *b = &G.db_busy[hd[k]];
+            uint64_t o = 0;
+            if (hm[k] == OCRMODE_EW) { o = __sync_fetch_and_add(b, BUSY_EW); if (o) __sync_fetch_and_add(&G.overlaps, 1); }
+            else if (hm[k] == OCRMODE_RW) { o = __sync_fetch_and_add(b, BUSY_RW); if (o >= BUSY_EW || (o & (BUSY_RW - 1))) __sync_fetch_and_add(&G.overlaps, 1); }
+            else if (hm[k] == OCRMODE_CONST) { o = __sync_fetch_and_add(b, BUSY_CONST); if (o >= BUSY_RW) __sync_fetch_and_add(&G.overlaps, 1); }
+        }
+        for (uint32_t k = 0; k < nh; ++k) { /* a holder comes after every holder it excludes */
+            volatile long long *c = &G.db_clk[3 * hd[k]];
+            long long need = -1;
+            if (hm[k] == OCRMODE_EW) { need = c[0]; if (c[1] > need) need = c[1]; if (c[2] > need) need = c[2]; }
+            else if (hm[k] == OCRMODE_RW) { need = c[0]; if (c[2] > need) need = c[2]; }
+            else if (hm[k] == OCRMODE_CONST) { need = c[0]; if (c[1] > need) need = c[1]; }
+            if (need + 1 > lvl) lvl = need + 1;
+        }
+        for (uint32_t k = 0; k < nh; ++k) {
+            volatile long long *c = &G.db_clk[3 * hd[k]];
+            if (hm[k] == OCRMODE_EW) clk_max(&c[0], lvl); else if (hm[k] == OCRMODE_RW) clk_max(&c[1], lvl); else if (hm[k] == OCRMODE_CONST) clk_max(&c[2], lvl);
+        }
+        struct timespec ts = { 0, 20000 }; nanosleep(&ts, NULL); /* stay inside long enough for an unkept exclusion to show */
+    }
     ocrGuid_t ret = NULL_GUID;
     switch (OCRBODY_KIND(e->body)) {
     case OCRBODY_HASH: {
@@ -152,6 +201,9 @@ static ocrGuid_t bodyEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) 
         if (op->op == OCROP_SATISFY) do_satisfy(op, id, lvl, depv);
         else if (op->op == OCROP_EVT_DESTROY) ocrEventDestroy(ref_guid(op->a, id, depv));
     }
+    for (uint32_t k = 0; k < nh; ++k)
+        __sync_fetch_and_sub(&G.db_busy[hd[k]], hm[k] == OCRMODE_EW ? BUSY_EW : hm[k] == OCRMODE_RW ? BUSY_RW : hm[k] == OCRMODE_CONST ? BUSY_CONST : 0ULL);
+    free(hd);
     if (e->body & OCRBODY_F_OUTEVT) clk_note(G.hdr.n_evt + id, lvl); /* epilogue satisfies it, hc-task.c:1813-1830 */
     G.level[id] = (int32_t)lvl; G.val[id] = v;
     __sync_fetch_and_add(&G.n_fired, 1);
@@ -160,6 +212,7 @@ static ocrGuid_t bodyEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) 
         dump_results();
         printf("REPLAY fired=%u edges=%llu resolve_s=%.6f sat_per_s=%.1f\n", G.n_fired,
                (unsigned long long)G.n_sat_edges, dt, dt > 0 ? G.n_sat_edges / dt : 0.0);
+        if (G.lockable) printf("REPLAY_LOCKABLE overlaps=%u\n", G.overlaps);
         fflush(stdout);
         ocrShutdown();
     }
@@ -249,6 +302,11 @@ static void load_stream(const char *path) {
     G.slot_base = calloc(G.hdr.n_edt + 1, 8);
     for (uint32_t i = 0; i < G.hdr.n_edt; ++i) G.slot_base[i + 1] = G.slot_base[i] + G.edt[i].depc;
     G.slot_src = calloc(G.slot_base[G.hdr.n_edt] + 1, 8);
+    G.lockable = getenv("OCR_REPLAY_LOCKABLE") != NULL;
+    G.slot_mode = calloc(G.slot_base[G.hdr.n_edt] + 1, 1);
+    G.db_clk = malloc(8 * 3 * (size_t)(G.n_db_total + 1));
+    for (size_t i = 0; i < 3 * (size_t)(G.n_db_total + 1); ++i) G.db_clk[i] = -1;
+    G.db_busy = calloc(G.n_db_total + 1, 8);
     G.feed_ptr = calloc(G.n_evt_total + 2, 4);
     G.slot_gen = calloc(G.slot_base[G.hdr.n_edt] + 1, 4);
     G.chan_clk = calloc(G.n_evt_total + 1, sizeof(long long *));
@@ -275,6 +333,7 @@ static void load_stream(const char *path) {
             if (dc == OCRREF_EDT) {
                 if (!pass) {
                     G.slot_src[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = op->a; G.n_sat_edges++;
+                    G.slot_mode[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = op->mode;
                     if (src_evt && evt_kind(evt_index(op->a)) == OCREVT_CHANNEL)
                         G.slot_gen[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = G.chan_nreg[evt_index(op->a)]++;
                 }

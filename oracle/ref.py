@@ -52,7 +52,8 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def run_restatement(s: OpStream, return_stats=False):
+def run_restatement(s: OpStream, return_stats=False, lockable=False):
+    """``lockable``: datablocks arbitrate their acquire modes like the cfg's datablockfactory=Lockable (else Regular)."""
     lib = _load()
     hdr = np.zeros(1, dtype=HDR_DT)
     hdr["magic"] = MAGIC
@@ -63,8 +64,8 @@ def run_restatement(s: OpStream, return_stats=False):
     evs = np.empty(s.n_evt_total, dtype=np.uint64)
     dbv = np.empty(s.n_db_total, dtype=np.uint64)
     stats = np.zeros(16, dtype=np.uint64)
-    rc = lib.ocrref_run(_p(hdr), _p(s.edt), _p(s.evt), _p(s.db_init), _p(s.main), _p(s.script),
-                        _p(level), _p(val), _p(evs), _p(dbv), _p(stats))
+    rc = lib.ocrref_run2(_p(hdr), _p(s.edt), _p(s.evt), _p(s.db_init), _p(s.main), _p(s.script),
+                         _p(level), _p(val), _p(evs), _p(dbv), _p(stats), ctypes.c_uint32(1 if lockable else 0))
     assert rc == 0
     r = Result(level, val, evs, dbv)
     return (r, stats) if return_stats else r
@@ -74,21 +75,30 @@ def reference_available(flavour="dbg"):
     return os.path.exists(os.path.join(REF_DIR, f"ocr_replay_{flavour}"))
 
 
-def run_reference(s: OpStream, workers=1, guid="COUNTED_MAP", flavour="dbg", timeout=600, want_result=True):
-    """Replay ``s`` on the reference runtime. Returns (Result|None, info dict with the timing line)."""
+def run_reference(s: OpStream, workers=1, guid="COUNTED_MAP", flavour="dbg", timeout=600, want_result=True, db="Regular",
+                  lock_harness=None):
+    """Replay ``s`` on the reference runtime. Returns (Result|None, info dict with the timing line).
+    ``db``: the cfg's datablock factory, "Regular" or "Lockable" (the latter also switches the harness's clocks to
+    count datablock hand-overs and makes it watch for overlapping holders; see oracle/ocr_replay.c)."""
     from oracle.mkcfg import cfg
     exe = os.path.join(REF_DIR, f"ocr_replay_{flavour}")
     with tempfile.TemporaryDirectory(prefix="ocrref_") as td:
         ops, res, cf = (os.path.join(td, n) for n in ("s.ops", "s.res", "m.cfg"))
         s.to_file(ops)
         with open(cf, "w") as f:
-            f.write(cfg(workers, guid))
+            f.write(cfg(workers, guid, db))
+        env = dict(os.environ)
+        if (db == "Lockable") if lock_harness is None else lock_harness:
+            env["OCR_REPLAY_LOCKABLE"] = "1"
         out = subprocess.run([exe, "-ocr:cfg", cf, ops, res if want_result else "-"], capture_output=True,
-                             text=True, timeout=timeout)
+                             text=True, timeout=timeout, env=env)
         if out.returncode != 0:
             raise RuntimeError(f"reference replay failed rc={out.returncode}: {out.stdout[-500:]} {out.stderr[-500:]}")
         m = re.search(r"REPLAY fired=(\d+) edges=(\d+) resolve_s=([\d.]+) sat_per_s=([\d.]+)", out.stdout)
         info = dict(fired=int(m.group(1)), edges=int(m.group(2)), resolve_s=float(m.group(3)),
                     sat_per_s=float(m.group(4))) if m else {}
+        m = re.search(r"REPLAY_LOCKABLE overlaps=(\d+)", out.stdout)
+        if m:
+            info["overlaps"] = int(m.group(1))
         r = Result.from_file(res) if want_result else None
     return r, info
