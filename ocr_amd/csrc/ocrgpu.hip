@@ -77,12 +77,6 @@ struct Rec { u32 dst, payload, slot, flags; };      // one pending satisfy: dst 
 // in chan_sat[].  counted[x] = [satisfies so far:32 | registrations so far:32], one atomic per op.
 struct ChanRec { u32 cap, wait_base, sat_base, pad; };
 struct Script { u32 target, payload, slot, op_kind; }; // op | payload_kind<<8
-// Lockable datablock (lockable-datablock.h): state = modeLock << 30 | numUsers; heads of the three LIFO waiter lists
-// (EDT index + 1; the link to the next waiter sits in the upper half of the waiting EDT's `val`)
-struct DbLock { u32 state, ew, itw, ro; };
-#define DBL_EW 1u
-#define DBL_ITW 2u
-#define DBL_USERS 0x3FFFFFFFu
 // A satisfy whose destination lives on another partition (GPU): what crosses xGMI instead of the reference's
 // marshalled ocrPolicyMsg_t (hc-dist-policy.c:2208, mpi-comm-platform.c:1055).  The datablock travels by value
 // (16-byte DBs), the way hc-dist's ProxyDb_t clones it on acquire (hc-dist-policy.c:382-700).
@@ -95,6 +89,13 @@ static_assert(sizeof(SendRec) == 32, "SendRec is 32 bytes");
 #define XF_ACTIVATE 32u  // guid = a COUNTED event here: a held-back registration of a remote EDT has now been made
 #define RF_REMOTE 8u     // waiter flag (with bit0 clear): lo = index into rdst[]; bit2 = dst is an EDT, bit1 = MODE_NULL
 struct RemoteDst { u64 guid; u32 slot, flags; };
+
+// Lockable datablock (lockable-datablock.h): state = modeLock << 30 | numUsers; heads of the three LIFO waiter lists
+// (EDT index + 1; the link to the next waiter sits in the upper half of the waiting EDT's `val`)
+struct DbLock { u32 state, ew, itw, ro; };
+#define DBL_EW 1u
+#define DBL_ITW 2u
+#define DBL_USERS 0x3FFFFFFFu
 
 // Phase state of launch K.  EVERY workgroup of launch K derives it from state[(K-1)&1] and the append counters
 // of launch K-1 (all stable once K-1 has ended), so no workgroup waits for another: no ticket, no grid barrier.
@@ -110,7 +111,10 @@ struct alignas(128) Ctrl {
     u32 r_tail; u32 pad2[31];   // atomics (own cache lines)
     u32 q_tail; u32 pad3[31];
     u32 log_tail; u32 rdst_tail; u32 chan_count, chan_wait_used, chan_sat_used; u32 pad4[27];
-    u32 err[8]; u32 pad5[24];
+    u32 err[8];
+    DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB only (else null): lock word + waiter lists per datablock; access mode per
+                                          // EDT pre-slot.  Kept here, not in Dev: the hot kernel's argument block stays as small as it was
+    u32 pad5[20];
     // during a run
     State state[2];
     Cnt cnt_r[3], cnt_q[3];     // launch K appends through cnt_*[K%3]; launch K+1 reads them; launch K zeroes [(K+1)%3]
@@ -132,7 +136,6 @@ struct Dev {
     u32 *log_src; u64 *log_rec; // registration log the CSR is built from
     // datablocks (explicit [0,max_db) then the output DB of EDT e at max_db+e): {value, tag}
     ulonglong2 *db;
-    DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB only: lock word + waiter lists per datablock; access mode per EDT pre-slot
     // work lists
     u32 *fired;                 // fired/ready log, grouped by level
     u32 *level_start;           // level_start[L] = offset in `fired`
@@ -222,7 +225,7 @@ __device__ void emit_remote_raw(const Dev &d, u64 guid, u32 slot, u32 xflags, u6
 struct Step { // per-launch constants, identical in every workgroup
     u32 mode, r_begin, r_end, q_begin, q_end, r_base, q_base; u32 *cnt_r, *cnt_q;
 };
-template <bool NANNY>
+template <bool NANNY, bool LOCKABLE>
 __device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, const Step &S, u32 edt, u32 slot, u32 payload, u32 flags) {
     EdtLine *L = &d.edt[edt];
     u32 word = (flags & RF_MODE_NULL) ? 0u : payload;
@@ -236,16 +239,16 @@ __device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, const Step &S, u3
         *sp = word | SLOT_MARK;
     }
     const u32 old = atomicSub(&L->pending, 1u);
-    if (old & (PEND_LAZY | PEND_ACQ)) { // rare
-        if (old & PEND_LAZY) { // this EDT's frontier is tracked (COUNTED accounting); the walk runs in the next EVENTS phase
-            const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
-            if (qi < d.q_cap) d.q[qi] = Rec{edt, 0u, slot, RF_LAZYWALK}; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
-        }
-        if ((old & PEND_ACQ) && (old & PEND_MASK) == 1u) { // Lockable datablocks: all satisfied -> acquire first (taskAllDepvSatisfied)
+    if (old & PEND_LAZY) { // rare: this EDT's frontier is tracked (COUNTED accounting); the walk runs in the next EVENTS phase
+        const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
+        if (qi < d.q_cap) d.q[qi] = Rec{edt, 0u, slot, RF_LAZYWALK}; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+    }
+    if (LOCKABLE) { // Lockable datablocks (every EDT carries PEND_ACQ): all satisfied -> acquire first (taskAllDepvSatisfied)
+        if ((old & PEND_MASK) == 1u) {
             const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
             if (qi < d.q_cap) d.q[qi] = Rec{edt, 0u, 0u, RF_ACQUIRE}; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
-            return false;
         }
+        return false;
     }
     return (old & PEND_MASK) == 1u;
 }
@@ -354,7 +357,7 @@ __device__ __forceinline__ size_t acq_index(const Dev &d, u32 edt, u32 depc, u32
 }
 // true = acquired; false = OCR_EBUSY: queued on the list of its mode (push-front like the reference's lists)
 __device__ __forceinline__ bool db_acquire(const Dev &d, u32 db, u32 mode, u32 e) {
-    DbLock *B = &d.dbl[db];
+    DbLock *B = &d.ctrl->dbl[db];
     u32 o = atomicAdd(&B->state, 0u);
     for (;;) {
         const u32 lock = o >> 30;
@@ -377,7 +380,7 @@ __device__ __forceinline__ bool acq_walk(const Dev &d, u32 e) {
     EdtLine *L = &d.edt[e];
     const u32 depc = L->depc;
     const u32 *sl = depc <= INLINE_SLOTS ? L->slot : d.slots + L->slot[0];
-    const unsigned char *md = d.acq_mode + acq_index(d, e, depc, L->slot[0], 0u);
+    const unsigned char *md = d.ctrl->acq_mode + acq_index(d, e, depc, L->slot[0], 0u);
     u32 last = (u32)L->val;
     for (;;) {
         u32 best = 0xFFFFFFFFu, bm = 0; // the next datablock in ascending order; named twice = the mode of its lowest pre-slot (stable sort :459-477)
@@ -391,7 +394,7 @@ __device__ __forceinline__ bool acq_walk(const Dev &d, u32 e) {
 // lockableRelease: `push(edt)` queues an RF_ACQUIRE record for every waiter the datablock is handed to
 template <class Push>
 __device__ __forceinline__ void db_release(const Dev &d, u32 db, Push push) {
-    DbLock *B = &d.dbl[db];
+    DbLock *B = &d.ctrl->dbl[db];
     const u32 o = atomicSub(&B->state, 1u);
     if ((o & DBL_USERS) == 0u) { atomicAdd(&B->state, 1u); atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; } // released more often than acquired
     if ((o & DBL_USERS) != 1u) return;
@@ -526,7 +529,7 @@ __device__ void emit_remote_raw(const Dev &d, u64 guid, u32 slot, u32 xflags, u6
 // consecutive entries of the ready log up front (one atomic, issued before the waiter loads so it costs no
 // extra round trip) and lane t writes entry t: the EDT it made ready, or INVALID.  Compaction happens on
 // the read side (the FIRE pass skips holes), where it is a ballot instead of a dependent atomic.
-template <bool NANNY>
+template <bool NANNY, bool LOCKABLE>
 __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 total, u32 *lds_base, u64 &n_edt_sat, u64 &n_evt_sat) {
     Ctrl *c = d.ctrl;
     u32 rbase = 0;
@@ -543,7 +546,7 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
             u64 w = d.waiters[seg[lo].row + (t - start)];
             u32 whi = (u32)(w >> 32);
             dst = (u32)w; flags = whi >> 28; slot = whi & 0x0FFFFFFFu; payload = seg[lo].payload;
-            if (flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, S, dst, slot, payload, flags); ++n_edt_sat; }
+            if (flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, dst, slot, payload, flags); ++n_edt_sat; }
             else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote(d, rd.guid, rd.slot, rd.flags, payload); }
             else {
                 to_evt = true; ++n_evt_sat;
@@ -624,7 +627,7 @@ __device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, 
 #endif
 
 // One launch = one phase.  K is the launch index (host counter): it selects the state / counter buffers.
-template <bool NANNY>
+template <bool NANNY, bool LOCKABLE>
 __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #ifdef OCRGPU_STAMPS
     u64 _t0 = __builtin_amdgcn_s_memrealtime();
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                         }
                     }
                 }
-                if (d.dbl && depc && !host_body) // Lockable datablocks: the body has run, its datablocks go back (host bodies: ocrgpu_edt_release_dbs)
+                if (LOCKABLE && depc && !host_body) // Lockable datablocks: the body has run, its datablocks go back (host bodies: ocrgpu_edt_release_dbs)
                     release_all(d, sl, depc, [&](u32 w) {
                         const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
                         if (qi < d.q_cap) d.q[qi] = Rec{w, 0u, 0u, RF_ACQUIRE}; else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             seg[threadIdx.x] = sg;
             __syncthreads();
             STAMP(2);
-            if (total) fan_out<NANNY>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
+            if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             else __syncthreads();
             STAMP(3);
             if (mine && !body_first && OCRBODY_KIND(body) != OCRBODY_HOST) run_body(d, e, id, depc, sl, gb);
@@ -791,8 +794,8 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (act) {
                 r = d.q[i];
                 if (r.flags & RF_LAZYWALK) lazy_walk(d, r.dst, r.slot);
-                else if (r.flags & RF_ACQUIRE) ready = acq_walk(d, r.dst);
-                else if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY>(d, S, r.dst, r.slot, r.payload, r.flags); ++n_edt_sat; }
+                else if (LOCKABLE && (r.flags & RF_ACQUIRE)) ready = acq_walk(d, r.dst);
+                else if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, r.dst, r.slot, r.payload, r.flags); ++n_edt_sat; }
                 else if (!(r.flags & RF_FIRED)) { kind = (*evt_state(d, r.dst) >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
             }
             u32 ri = S.r_base + wave_append(S.cnt_r, ready);
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             sg.end_off = incl;
             seg[threadIdx.x] = sg;
             __syncthreads();
-            if (total) fan_out<NANNY>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
+            if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             else __syncthreads();
         }
     }
@@ -930,7 +933,7 @@ __global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, con
     if (i >= n) return;
     u32 e = first_idx + (u32)i, dc = depc[i], b = body[i] & 0xFFFFu;
     EdtLine L;
-    L.pending = dc | ((d.dbl && dc) ? PEND_ACQ : 0u); L.depc = dc; L.body = b;
+    L.pending = dc | ((d.ctrl->dbl && dc) ? PEND_ACQ : 0u); L.depc = dc; L.body = b;
     L.param0 = param0 ? param0[i] : (u64)e; L.val = 0;
     L.out_row = 0; L.out_deg = 0;
     L.out_state = (b & OCRBODY_F_OUTEVT) ? (ST_LIVE | (OCREVT_ONCE << 8)) : (u32)ST_ABSENT; // ONCE output event (hc-task.c:940-959)
@@ -1044,8 +1047,9 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
     if (!resolve_dst(d, dg, slot[i], didx, dflag, dslot)) { bad_op(d); return; }
     const bool d_edt = (dflag & RF_DST_EDT) != 0;
     u32 mnull = (d_edt && mode[i] == OCRMODE_NULL) ? RF_MODE_NULL : 0u;
-    if (d.acq_mode && d_edt && s != OCRGPU_NULL_GUID) // registerSignalerTaskHc records the mode (hc-task.c:1373); a NULL source does not
-        d.acq_mode[acq_index(d, didx, (dflag & RF_INLINE) ? 0u : INLINE_SLOTS + 1u, d.edt[didx].slot[0], dslot)] = (unsigned char)mode[i];
+    unsigned char *const acq_mode = d.ctrl->acq_mode;
+    if (acq_mode && d_edt && s != OCRGPU_NULL_GUID) // registerSignalerTaskHc records the mode (hc-task.c:1373); a NULL source does not
+        acq_mode[acq_index(d, didx, (dflag & RF_INLINE) ? 0u : INLINE_SLOTS + 1u, d.edt[didx].slot[0], dslot)] = (unsigned char)mode[i];
     if (s == OCRGPU_NULL_GUID) { q_push(d, Rec{didx, 0u, dslot, dflag}); return; } // == satisfy(dst, slot, NULL)
     u64 sv = gtab_get(d, s);
     u32 sk = OCRGPU_GUID_KIND(s);
@@ -1424,6 +1428,7 @@ struct ocrgpu_engine {
     hipEvent_t ev0, ev1; bool have_events; u32 step_grid; u32 launch_index; u64 fired_cap; bool defer_drain; u32 *send_cnt_dev;
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
     u32 *pinned_done; u32 apply_flip; hipEvent_t apply_ev[2];
+    DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB: the device tables (the device finds them through Ctrl)
     u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
 };
 
@@ -1524,7 +1529,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->snap.dbl = nullptr; e->have_events = false;
-    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr;
+    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr; e->dbl = nullptr; e->acq_mode = nullptr;
     e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->pop_cursor = e->snap_pop_cursor = 0; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
     { const char *mp = getenv("OCRGPU_SPREAD_WGS"); u32 v = mp ? (u32)atoi(mp) : 256u; d.spread_wgs = v < 1 ? 1u : (v > MAX_GRID ? (u32)MAX_GRID : v); }
@@ -1563,8 +1568,8 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.log_rec, 8 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.db, 16 * (size_t)n_db_total));
     if (cfg->flags & OCRGPU_F_LOCKABLE_DB) {
-        TRY(dalloc(e, (void **)&d.dbl, sizeof(DbLock) * (size_t)n_db_total));
-        TRY(dalloc(e, (void **)&d.acq_mode, (size_t)cfg->max_edt * INLINE_SLOTS + (size_t)d.max_slots));
+        TRY(dalloc(e, (void **)&e->dbl, sizeof(DbLock) * (size_t)n_db_total));
+        TRY(dalloc(e, (void **)&e->acq_mode, (size_t)cfg->max_edt * INLINE_SLOTS + (size_t)d.max_slots));
     }
     u64 fired_cap = (u64)cfg->max_edt + d.max_edges + 4096; if (fired_cap > 0xFFFFFFF0ull) fired_cap = 0xFFFFFFF0ull;
     e->fired_cap = fired_cap; d.fired_cap = (u32)fired_cap;
@@ -1583,6 +1588,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&e->tmp_c, 4 * (size_t)(tmpn + 4)));
     // ctrl.level starts at -1 (main-program satisfies are "level -1")
     Ctrl h; memset(&h, 0, sizeof h); h.level = 0xFFFFFFFFu; h.state[0].done = h.state[1].done = 1;
+    h.dbl = e->dbl; h.acq_mode = e->acq_mode;
     if (hipMemcpyAsync(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice, e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "ctrl init failed"); }
     // u32 index: [0,32) the polled State; [32, 32 + 32*1024) send counters of up to 1024 locations; [33000, 34000) small read-backs
     if (hipHostMalloc((void **)&e->pinned_done, 4 * 34816) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
@@ -1680,7 +1686,8 @@ static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool ti
     if (timing && e->have_events) HIPCHK(hipEventRecord(e->ev0, e->stream));
     for (;;) {
         for (u32 k = 0; k < batch; ++k, ++K) {
-            if (nanny) k_step<true><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false><<<grid, BLK, 0, e->stream>>>(d, K);
+            if (e->dbl) { if (nanny) k_step<true, true><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, true><<<grid, BLK, 0, e->stream>>>(d, K); }
+            else if (nanny) k_step<true, false><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false><<<grid, BLK, 0, e->stream>>>(d, K);
         }
         launched += batch;
         HIPCHK(hipMemcpyAsync(e->pinned_done, &d.ctrl->state[(K - 1) & 1], sizeof(State), hipMemcpyDeviceToHost, e->stream));
@@ -1907,7 +1914,7 @@ extern "C" int ocrgpu_edt_release_dbs(ocrgpu_engine_t *e, u64 n, const u64 *edt,
     ENTER(e);
     if (n == 0) return 0;
     if (!edt) FAIL(OCRGPU_EINVAL, "null array");
-    if (!e->d.dbl) FAIL(OCRGPU_EINVAL, "engine was not created with OCRGPU_F_LOCKABLE_DB");
+    if (!e->dbl) FAIL(OCRGPU_EINVAL, "engine was not created with OCRGPU_F_LOCKABLE_DB");
     int r = stage_reserve(e, rup(8 * n)); if (r) return r;
     const u64 *de; if ((r = stage_in(e, edt, n, where, &de))) return r;
     k_release_dbs<<<nblk(n), 256, 0, e->stream>>>(e->d, n, de);
@@ -2011,7 +2018,7 @@ extern "C" int ocrgpu_step_info(ocrgpu_engine_t *e, u64 *out4) {
 //      ocr/src/inc/ocr-comm-platform.h:55-199; the transport itself -- RCCL all-to-all -- is the caller's) ----
 extern "C" int ocrgpu_exchange_config(ocrgpu_engine_t *e, u32 n_locations, void *send_dev_buf, u64 records_per_dest, u64 max_remote_dsts) {
     ENTER(e);
-    if (e->d.dbl) FAIL(OCRGPU_EINVAL, "OCRGPU_F_LOCKABLE_DB arbitrates within one partition: not with an exchange configured");
+    if (e->dbl) FAIL(OCRGPU_EINVAL, "OCRGPU_F_LOCKABLE_DB arbitrates within one partition: not with an exchange configured");
     if (n_locations == 0 || n_locations > 1024 || e->cfg.location >= n_locations) FAIL(OCRGPU_EINVAL, "bad n_locations");
     if (n_locations > 1 && (!send_dev_buf || records_per_dest == 0 || records_per_dest > 0xFFFFFFFFull)) FAIL(OCRGPU_EINVAL, "send buffer required");
     Dev &d = e->d;
@@ -2096,9 +2103,9 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     Dev &d = e->d; Snapshot &s = e->snap;
     if (s.valid) { HIPCHK(hipStreamSynchronize(e->stream)); snap_free(s); }
     s.dbl = nullptr;
-    if (d.dbl) {
+    if (e->dbl) {
         HIPCHK(hipMalloc((void **)&s.dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt)));
-        HIPCHK(hipMemcpyAsync(s.dbl, d.dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt), hipMemcpyDeviceToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(s.dbl, e->dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt), hipMemcpyDeviceToDevice, e->stream));
     }
     HIPCHK(hipMalloc((void **)&s.edt, sizeof(EdtLine) * (size_t)e->n_edt + 64));
     HIPCHK(hipMalloc((void **)&s.evt, sizeof(EvtRec) * (size_t)e->n_evt + 64));
@@ -2137,7 +2144,7 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     e->pop_cursor = e->snap_pop_cursor;
     e->n_db = s.n_db; // proxy datablocks cloned from other partitions since the snapshot are dropped
     if (e->d.send_cnt) k_exchange_reset<<<1, 1024, 0, e->stream>>>(e->d);
-    if (d.dbl && s.dbl) HIPCHK(hipMemcpyAsync(d.dbl, s.dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt), hipMemcpyDeviceToDevice, e->stream));
+    if (e->dbl && s.dbl) HIPCHK(hipMemcpyAsync(e->dbl, s.dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.edt, s.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.evt, s.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     if (e->n_evt) HIPCHK(hipMemcpyAsync(d.counted, s.counted, 8 * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
