@@ -285,6 +285,33 @@ def layered_dag(n_edt: int, width: int, seed: int = SEED_BASE + 2, name=None) ->
                     name=name or f"layered_N{N}_W{width}", meta=meta)
 
 
+def lockable_layered(n_edt: int, width: int, n_db: int, seed: int = SEED_BASE + 0x10C) -> OpStream:
+    """config-2-shaped layered DAG whose EDTs also contend for ``n_db`` shared datablocks: every
+    EDT gets one more pre-slot, fed directly by datablock (r mod n_db) in mode EW / RW / CONST / RO (3 : 2 : 2 : 1).
+    Under the Regular datablock factory it resolves like layered_dag; under Lockable (OCRGPU_F_LOCKABLE_DB) the EDTs of a
+    layer that share a datablock are serialised by their acquire modes."""
+    s = layered_dag(n_edt, width, seed)
+    N = n_edt
+    edt = s.edt.copy()
+    extra_slot = edt["depc"][:N].copy()
+    edt["depc"][:N] += 1
+    r = splitmix64(seed ^ 0x10CAB1E, N)
+    which = (r % np.uint64(n_db)).astype(np.int64)
+    m = ((r >> np.uint64(40)) % np.uint64(8)).astype(np.int64)
+    mode = np.array([MODE_EW, MODE_EW, MODE_EW, MODE_RW, MODE_RW, MODE_CONST, MODE_CONST, MODE_RO], dtype=np.uint8)[m]
+    assert int(s.main["op"][-1]) == OP_SATISFY
+    main = np.concatenate([
+        make_ops(OP_DB_CREATE, np.arange(n_db)),
+        s.main[:-1],
+        make_ops(OP_ADD_DEP, ref(REF_DB, which), b=ref(REF_EDT, np.arange(N)), slot=extra_slot, mode=mode),
+        s.main[-1:],
+    ])
+    meta = dict(s.meta)
+    meta.update(kind="lockable_layered", n_db=n_db, n_satisfactions=s.meta["n_satisfactions"] + N)
+    return OpStream(edt, s.evt, 1000 + np.arange(n_db, dtype=np.uint64), main, s.script, s.sink_edt,
+                    name=f"lockable_N{N}_W{width}_D{n_db}", meta=meta)
+
+
 class Builder:
     """Write small op streams by hand (tests, examples): objects are plain ints, refs are made for you."""
 

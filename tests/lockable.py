@@ -133,32 +133,41 @@ def all_lockable():
 
 
 def holders(s):
-    """{db: [(edt, mode)]}: what each EDT acquires, from the stream's direct (db -> EDT pre-slot) dependences; the mode of
-    a datablock named on several pre-slots is that of its lowest pre-slot (stable sort)."""
+    """(db[], edt[], mode[]): what each EDT acquires, from the stream's direct (db -> EDT pre-slot) dependences; the mode of
+    a datablock named on several pre-slots of one EDT is that of its lowest pre-slot (stable sort)."""
     m = s.main
     sel = (m["op"] == OP_ADD_DEP) & (ref_cls(m["a"]) == REF_DB) & (ref_cls(m["b"]) == REF_EDT) & (m["mode"] != MODE_NULL)
-    first = {}
-    for a, bb, slot, mode in zip(ref_idx(m["a"][sel]), ref_idx(m["b"][sel]), m["slot"][sel], m["mode"][sel]):
-        k = (int(a), int(bb))
-        if k not in first or slot < first[k][0]:
-            first[k] = (int(slot), int(mode))
-    out = {}
-    for (d, e), (_, mode) in first.items():
-        out.setdefault(d, []).append((e, mode))
-    return out
+    db, edt = ref_idx(m["a"][sel]).astype(np.int64), ref_idx(m["b"][sel]).astype(np.int64)
+    slot, mode = m["slot"][sel].astype(np.int64), m["mode"][sel].astype(np.int64)
+    order = np.lexsort((slot, edt, db))
+    db, edt, mode = db[order], edt[order], mode[order]
+    first = np.ones(len(db), bool)
+    first[1:] = (db[1:] != db[:-1]) | (edt[1:] != edt[:-1])
+    return db[first], edt[first], mode[first]
 
 
 def check_levels(s, level, base_level):
     """Raise AssertionError unless `level` is a valid outcome of `s` under Lockable datablocks (see module docstring)."""
-    level = np.asarray(level)
-    base_level = np.asarray(base_level)
+    level = np.asarray(level).astype(np.int64)
+    base_level = np.asarray(base_level).astype(np.int64)
     assert ((level >= 0) == (base_level >= 0)).all(), "the same EDTs must fire"
     assert (level >= base_level).all(), "an EDT fired before its dependences allow"
-    for d, hs in holders(s).items():
-        by_level = {}
-        for e, mode in hs:
-            if mode != MODE_RO and level[e] >= 0:
-                by_level.setdefault(int(level[e]), []).append(mode)
-        for lv, modes in by_level.items():
-            ok = modes == [MODE_EW] or all(x == MODE_RW for x in modes) or all(x == MODE_CONST for x in modes)
-            assert ok, f"{s.name}: datablock {d} level {lv}: incompatible holders {modes}"
+    db, edt, mode = holders(s)
+    keep = (mode != MODE_RO) & (level[edt] >= 0)
+    db, lv, mode = db[keep], level[edt][keep], mode[keep]
+    if len(db) == 0:
+        return
+    order = np.lexsort((lv, db))
+    db, lv, mode = db[order], lv[order], mode[order]
+    new = np.ones(len(db), bool)
+    new[1:] = (db[1:] != db[:-1]) | (lv[1:] != lv[:-1])
+    gid = np.cumsum(new) - 1                               # one group per (datablock, level)
+    size = np.bincount(gid)
+    n_ew = np.bincount(gid, weights=(mode == MODE_EW))
+    n_rw = np.bincount(gid, weights=(mode == MODE_RW))
+    n_const = np.bincount(gid, weights=(mode == MODE_CONST))
+    ok = ((n_ew == 1) & (size == 1)) | (n_rw == size) | (n_const == size)
+    if not ok.all():
+        g = int(np.nonzero(~ok)[0][0])
+        i = int(np.nonzero(gid == g)[0][0])
+        raise AssertionError(f"{s.name}: datablock {int(db[i])} level {int(lv[i])}: incompatible holders {mode[gid == g].tolist()}")

@@ -98,3 +98,17 @@ def test_host_bodies_release_through_the_api():
     st = eng.stats()
     assert sum(st.err) == 0
     eng.close()
+
+
+def test_contended_layered_dag_200k():
+    """config-2-shaped DAG, 200 000 EDTs in 100 layers, every EDT also wants one of 512 shared datablocks in a random mode:
+    the dependences alone give 101 levels, the arbitration several hundred."""
+    from ocr_amd.engine import F_LOCKABLE_DB, run_stream
+    from ocr_amd.opstream import lockable_layered
+    s = lockable_layered(200_000, 2000, 512)
+    base = _restatement(s)
+    r, st = run_stream(s, flags=F_LOCKABLE_DB)
+    assert sum(st.err) == 0 and int(st.fired) == s.n_edt
+    assert (r.val == base.val).all() and (r.evt_state == base.evt_state).all() and (r.db_val == base.db_val).all()
+    L.check_levels(s, r.level, base.level)
+    assert int(st.levels) > int(base.level.max()) + 1

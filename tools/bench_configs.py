@@ -27,6 +27,8 @@ def make(spec):
         return op.powerlaw_dag(a[0])
     if k == "layered":
         return op.layered_dag(a[0], a[1])
+    if k == "lockable":   # lockable:N:width:n_db -- layered DAG + contended datablocks, run with OCRGPU_F_LOCKABLE_DB
+        return op.lockable_layered(a[0], a[1], a[2])
     raise SystemExit(f"unknown workload {spec}")
 
 
@@ -46,7 +48,8 @@ def run(spec, steps=3, warmup=1, parity=True):
     start_op = s.main[-1:]
     built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
     t0 = time.time()
-    prog = engine.StreamProgram(built, device=0, flags=engine.F_TIMING).build()
+    lockable = spec.startswith("lockable")
+    prog = engine.StreamProgram(built, device=0, flags=engine.F_TIMING | (engine.F_LOCKABLE_DB if lockable else 0)).build()
     eng = prog.eng
     eng.snapshot()
     eng.sync()
@@ -102,8 +105,23 @@ def run(spec, steps=3, warmup=1, parity=True):
         from oracle import ref as O            # checker only
         t0 = time.time()
         ref = O.run_restatement(s)
-        diff = prog.result().diff(ref)
-        out["parity"] = "bit-exact vs CPU restatement" if not diff else f"MISMATCH {diff[:3]}"
+        got = prog.result()
+        if lockable:   # who wins a datablock is a race (here and in the reference): levels through the checker, the rest exactly
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+            import lockable as L
+            same = (got.val == ref.val).all() and (got.evt_state == ref.evt_state).all() and (got.db_val == ref.db_val).all()
+            try:
+                L.check_levels(s, got.level, ref.level)
+                lv_ok = True
+            except AssertionError as ex:
+                lv_ok = str(ex)
+            r2, st2 = O.run_restatement(s, return_stats=True, lockable=True)
+            out["levels_regular"], out["levels_restatement_lockable"] = int(ref.level.max()) + 1, int(st2[0])
+            out["parity"] = ("values/events/DBs bit-exact vs CPU restatement, levels valid under the Lockable checker"
+                             if same and lv_ok is True else f"MISMATCH same={same} levels={lv_ok}")
+        else:
+            diff = got.diff(ref)
+            out["parity"] = "bit-exact vs CPU restatement" if not diff else f"MISMATCH {diff[:3]}"
         out["restatement_s"] = round(time.time() - t0, 2)
     print(json.dumps(out), flush=True)
     del prog, eng
