@@ -138,6 +138,10 @@ def main():
                          "us_per_launch": step_kernel_s / launches * 1e6,
                          "alg_bytes_per_resolve": alg_bytes, "kernel_s_per_resolve": step_kernel_s},
         }
+        # the limit that actually binds scattered slot counting (SURVEY.md s8d "second roofline"): returning device-scope
+        # atomics on random 64-byte lines, measured on an MI355X with tools/latbench.hip: 27e9 per second
+        out["roofline_atomics"] = {"bound": "scattered device-scope atomics (measured, tools/latbench.hip)", "achieved": n_sat / step_kernel_s / 1e9,
+                                   "peak": 27.0, "unit": "G atomics/s", "frac": n_sat / step_kernel_s / 27e9}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
     if world > 1:
@@ -267,7 +271,7 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     dist.destroy_process_group()
 
 
-def profiled_traffic(args, tag="r01d_config2"):
+def profiled_traffic(args, tag="r01e_config2"):
     """HBM bytes per k_step launch from the committed PMC passes (profiles/<tag>_pmc_summary.txt: FETCH_SIZE and
     WRITE_SIZE in KB, separate rocprofv3 --pmc runs of this same workload).  Counters cannot be read inside this
     process, so the figure is the profiled one; None for any other workload shape."""
