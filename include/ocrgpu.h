@@ -84,7 +84,8 @@ typedef struct {
                                  * its ocrAddDependence named (DB_MODE_CONST / RW / EW / RO), waits in line on a busy one
                                  * and only then becomes ready; the level that fires it releases them (iterateDbFrontier
                                  * hc-task.c:484-544, lockableAcquireInternal / lockableRelease
-                                 * lockable-datablock.c:139-263, 330-507).  One partition only (no exchange).  Which of
+                                 * lockable-datablock.c:139-263, 330-507).  One partition only (no exchange); at most
+                                 * 4096 pre-slots per EDT (a larger ocrgpu_edt_create entry is a malformed op).  Which of
                                  * several contenders gets a datablock first is a race, as it is between the reference's
                                  * workers; everything but the levels of the contenders is deterministic.             */
 

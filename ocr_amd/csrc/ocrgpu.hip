@@ -96,6 +96,7 @@ struct DbLock { u32 state, ew, itw, ro; };
 #define DBL_EW 1u
 #define DBL_ITW 2u
 #define DBL_USERS 0x3FFFFFFFu
+#define LOCKABLE_MAX_DEPC 4096u // OCRGPU_F_LOCKABLE_DB: most pre-slots an EDT may have
 
 // Phase state of launch K.  EVERY workgroup of launch K derives it from state[(K-1)&1] and the append counters
 // of launch K-1 (all stable once K-1 has ended), so no workgroup waits for another: no ticket, no grid barrier.
@@ -932,6 +933,11 @@ __global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, con
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 e = first_idx + (u32)i, dc = depc[i], b = body[i] & 0xFFFFu;
+    if (d.ctrl->dbl && dc > LOCKABLE_MAX_DEPC) { // acq_walk / release_all are quadratic in depc: refuse what would not finish (the EDT does not exist)
+        atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); EdtLine Z; memset(&Z, 0, sizeof Z); Z.out_state = (u32)ST_ABSENT; d.edt[e] = Z;
+        if (!gin) { guids_out[i] = 0; if (outevt_out) outevt_out[i] = 0; if (outdb_out) outdb_out[i] = 0; }
+        return;
+    }
     EdtLine L;
     L.pending = dc | ((d.ctrl->dbl && dc) ? PEND_ACQ : 0u); L.depc = dc; L.body = b;
     L.param0 = param0 ? param0[i] : (u64)e; L.val = 0;

@@ -112,3 +112,14 @@ def test_contended_layered_dag_200k():
     assert (r.val == base.val).all() and (r.evt_state == base.evt_state).all() and (r.db_val == base.db_val).all()
     L.check_levels(s, r.level, base.level)
     assert int(st.levels) > int(base.level.max()) + 1
+
+
+def test_too_many_preslots_is_refused():
+    """The datablock walk is quadratic in depc: under OCRGPU_F_LOCKABLE_DB an EDT with more than 4096 pre-slots is a
+    malformed op (counted, no guid), not a kernel that never ends."""
+    from ocr_amd.engine import F_LOCKABLE_DB, Engine
+    eng = Engine(max_edt=4, max_evt=4, max_db=2, max_slots=20000, max_edges=64, flags=F_LOCKABLE_DB)
+    g, _, _ = eng.edt_create([4096, 4097], [0, 0])
+    assert g[0] != 0 and g[1] == 0
+    assert eng.stats().err[4] == 1      # ERR_BAD_OP
+    eng.close()
