@@ -123,3 +123,30 @@ def test_too_many_preslots_is_refused():
     assert g[0] != 0 and g[1] == 0
     assert eng.stats().err[4] == 1      # ERR_BAD_OP
     eng.close()
+
+
+def test_config_twins_bit_exact_under_lockable():
+    """Cholesky / stencil / layered twins: every hand-over is ordered by dependences, so the Lockable record is fixed
+    (the reference agrees at 1 and 4 workers, tests/test_oracle_lockable.py) and the engine must match it bit for bit,
+    levels included -- with datablocks arriving through events and FWD0 bodies rather than direct dependences."""
+    from ocr_amd import opstream as op
+    from ocr_amd.engine import F_LOCKABLE_DB, F_NANNY, run_stream
+    for s in (op.cholesky_dag(8), op.cholesky_dag(32), op.stencil_dag(16, 10), op.layered_dag(1000, 100)):
+        want = _restatement(s, lockable=True)
+        for fl in (F_LOCKABLE_DB, F_LOCKABLE_DB | F_NANNY):
+            r, st = run_stream(s, flags=fl)
+            assert sum(st.err) == 0 and want.diff(r) == [], (s.name, fl)
+
+
+@pytest.mark.parametrize("nanny", [True, False], ids=["nanny", "fast"])
+def test_fuzz_corpus_bit_exact_under_lockable(nanny):
+    """Every event kind, lazy frontier registration, channels, scripts, unfired EDTs -- with each EDT going through the
+    acquisition walk before it is made ready.  These programs never contend, so the record is the Regular one."""
+    import streams
+    from ocr_amd.engine import F_LOCKABLE_DB, F_NANNY, run_stream
+    for seed in range(streams.FUZZ_SEEDS):
+        for es in (False, True):
+            s = streams.random_stream(seed, 36, eager_safe=es)
+            want = _restatement(s, lockable=True)
+            r, st = run_stream(s, flags=F_LOCKABLE_DB | (F_NANNY if nanny else 0))
+            assert sum(st.err) == 0 and want.diff(r) == [], (seed, es, list(st.err), want.diff(r)[:3])
