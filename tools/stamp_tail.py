@@ -63,7 +63,8 @@ if __name__ == "__main__":
         raise SystemExit
     import torch  # noqa: F401  (before libocrgpu: one HIP runtime per process)
     from ocr_amd import engine, opstream
-    s = opstream.layered_dag(10_000_000, 10_000)
+    n, w = int(os.environ.get("STAMP_N", 10_000_000)), int(os.environ.get("STAMP_W", 10_000))   # a wide level: STAMP_W=100000
+    s = opstream.layered_dag(n, w)
     built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
     prog = engine.StreamProgram(built, device=0, flags=0).build()
     eng = prog.eng
