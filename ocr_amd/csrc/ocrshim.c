@@ -575,6 +575,9 @@ static void *pack_args(int argc, char **argv, u64 *len_out) {
  * body that blocks (ocrLegacyBlockProgress) keeps calling run_one() from inside, so the EDTs popped with it still run. */
 static u64 *rq_p0, *rq_dg, *rq_dv; static u32 *rq_dc, *rq_df; static size_t rq_cap_e, rq_cap_d; static u64 rq_n, rq_pos;
 static u64 n_levels, n_bodies;
+/* OCRSHIM_LOCKABLE=1 (the cfg's datablockfactory=Lockable): the engine arbitrates datablock acquire modes
+ * (OCRGPU_F_LOCKABLE_DB); the EDTs whose bodies ran since the last refill give their datablocks back before the next step */
+static int g_lockable; static u64 *rel_g; static size_t rel_n, rel_cap;
 
 static int shim_init(void) {
     g_verbose = (int)env_u64("OCRSHIM_VERBOSE", 0);
@@ -586,6 +589,8 @@ static int shim_init(void) {
     cfg.max_edges = env_u64("OCRSHIM_MAX_EDGES", 1u << 23);
     cfg.location = 0;
     cfg.flags = env_u64("OCRSHIM_NANNY", 1) ? OCRGPU_F_NANNY : 0; /* user programs: report double satisfies (hc-task.c:1243) */
+    g_lockable = (int)env_u64("OCRSHIM_LOCKABLE", 0); rel_n = 0;
+    if (g_lockable) cfg.flags |= OCRGPU_F_LOCKABLE_DB;
     /* a second bring-up in one process (legacy blocks, ocr-legacy.h:74) starts from nothing */
     ++init_epoch;
     g_shutdown = g_exit_code = 0;
@@ -608,6 +613,7 @@ static double t_refilled;   /* when the run queue was last filled: the time unti
 static int refill(void) {
     if (t_refilled != 0.0) t_bodies += now_s() - t_refilled;
     for (;;) {
+        if (rel_n) { CHK(ocrgpu_edt_release_dbs(G, rel_n, rel_g, OCRGPU_HOST)); rel_n = 0; } /* taskEpilogue's release loop, hc-task.c:1723-1751 */
         flush();
         u64 has_ready = 0, pending = 0;
         double tt = now_s();
@@ -652,6 +658,10 @@ static int run_one(void) {
     body_begin(&t);
     ocrGuid_t ret = t.fn(t.paramc, t.paramv, t.depc, depv);
     body_end(&t, (u64)ret.guid);
+    if (g_lockable && t.depc) {
+        if (rel_n == rel_cap) { rel_cap = rel_cap ? 2 * rel_cap : 1024; rel_g = xrealloc(rel_g, 8 * rel_cap); }
+        rel_g[rel_n++] = t.guid;
+    }
     free(tasks[ti].paramv); tasks[ti].paramv = NULL;
     if (depv != small) free(depv);
     ++n_bodies;

@@ -19,13 +19,12 @@ UNSUPPORTED = set()
 RUNNABLE = sorted(n for n, e in FIX.items() if e.get("shim_builds") and n not in UNSUPPORTED)
 
 
-@pytest.mark.parametrize("name", RUNNABLE)
-def test_reference_program(name):
+def _check(name, env=None):
     exe = os.path.join(BIN, name)
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/shimtests not built (python oracle/build_shimtests.py)")
     want = FIX[name]
-    r = subprocess.run([exe] + list(want.get("args", [])), capture_output=True, text=True, timeout=60)
+    r = subprocess.run([exe] + list(want.get("args", [])), capture_output=True, text=True, timeout=60, env=env)
     if want["rc"] == 0:
         assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
         norm = lambda lines: sorted(re.sub(r"0x[0-9a-fA-F]+", "0xGUID", ln) for ln in lines)  # guid VALUES differ between runtimes
@@ -37,6 +36,28 @@ def test_reference_program(name):
         assert norm(got) == norm(exp), (r.stdout[-800:], want["stdout"][-10:])
     else:  # programs the reference rejects (asserts): the shim must not report success either
         assert r.returncode != 0, (r.stdout[-500:], r.stderr[-500:])
+
+
+@pytest.mark.parametrize("name", RUNNABLE)
+def test_reference_program(name):
+    _check(name)
+
+
+def test_reference_programs_with_lockable_datablocks():
+    """The same programs with OCRSHIM_LOCKABLE=1: the engine arbitrates the acquire modes the programs name
+    (OCRGPU_F_LOCKABLE_DB) and libocrshim reports each body's end with ocrgpu_edt_release_dbs -- the reference's own
+    exclusive-write programs (dist/testDistDbEw*.c, testDistDbEwRo*.c: EW writers, RO / CONST readers that check a
+    datablock is never seen half written) among them.  Same exit codes and console lines as under Regular datablocks."""
+    env = dict(os.environ, OCRSHIM_LOCKABLE="1")
+    for name in RUNNABLE:
+        _check(name, env)
+    # the arbitration is really on: testDistDbEw2's 40 exclusive writers of one datablock take a level each (2 levels without)
+    exe = os.path.join(BIN, "testDistDbEw2")
+    levels = {}
+    for lock in ("0", "1"):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=60, env=dict(os.environ, OCRSHIM_LOCKABLE=lock, OCRSHIM_VERBOSE="1"))
+        levels[lock] = int(re.search(r"levels=(\d+)", r.stderr).group(1))
+    assert levels["0"] < 10 and levels["1"] >= 41, levels
 
 
 def test_fib20():
