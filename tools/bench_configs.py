@@ -27,6 +27,11 @@ def make(spec):
         return op.powerlaw_dag(a[0])
     if k == "layered":
         return op.layered_dag(a[0], a[1])
+    if k == "layerednop":   # config 2's DAG with NOP bodies: dependence resolution alone, no datablock checksums
+        s = op.layered_dag(a[0], a[1])
+        n = a[0]
+        s.edt["body"][:n] = op.BODY_NOP | op.BODY_F_OUTEVT
+        return s
     if k == "lockable":   # lockable:N:width:n_db -- layered DAG + contended datablocks, run with OCRGPU_F_LOCKABLE_DB
         return op.lockable_layered(a[0], a[1], a[2])
     raise SystemExit(f"unknown workload {spec}")
