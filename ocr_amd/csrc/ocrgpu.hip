@@ -103,12 +103,14 @@ struct DbLock { u32 state, ew, itw, ro; };
 struct alignas(128) State {
     u32 mode, level, r_begin, r_end, q_begin, q_end, done, allow_fire;
     u32 r_total, q_total;   // log positions where this launch's appends start
-    u32 n_levels, force_level, pad[20];
+    u32 n_levels, force_level;
+    u32 b_begin, b_end;     // ready-log range of the level fired by this launch whose bodies were left for the next launch
+    u32 pad[18];
 };
 struct alignas(128) Cnt { u32 v; u32 pad[31]; };
 struct alignas(128) Ctrl {
     // between runs ("absolute" view, used by the API kernels and by k_begin / k_end)
-    u32 level, r_end, q_begin, pad0, n_levels, pad1[27];
+    u32 level, r_end, q_begin, pad0, n_levels, b_begin, b_end, pad1[25];
     u32 r_tail; u32 pad2[31];   // atomics (own cache lines)
     u32 q_tail; u32 pad3[31];
     u32 log_tail; u32 rdst_tail; u32 chan_count, chan_wait_used, chan_sat_used; u32 pad4[27];
@@ -618,6 +620,30 @@ __device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, 
     d.edt[e].val = v; // == the output DB's value (a live DB only for HASH bodies)
 }
 
+// Bodies left over by the previous launch (State.b_begin..b_end): helper workgroup h of nh walks the range.  The EDT
+// lines are read again -- off the critical path, by workgroups that would otherwise have left at once.
+__device__ void deferred_bodies(const Dev &d, u32 b_begin, u32 b_end, u32 h, u32 nh) {
+    for (u32 i = b_begin + h * BLK + threadIdx.x; i < b_end; i += nh * BLK) {
+        const u32 e = d.fired[i];
+        if (e == INVALID) continue;
+        const EdtLine L = d.edt[e];
+        if (OCRBODY_KIND(L.body) == OCRBODY_HOST) continue;
+        const u32 *sl; u32 pw[8]; ulonglong2 gb[8];
+        if (L.depc <= INLINE_SLOTS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pw[k] = L.slot[k] & 0x7FFFFFFFu;
+            pw[6] = pw[7] = 0; sl = d.edt[e].slot;
+        } else {
+            sl = d.slots + L.slot[0];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pw[k] = (u32)k < L.depc ? (sl[k] & 0x7FFFFFFFu) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
+        run_body(d, e, L.param0, L.depc, sl, gb);
+    }
+}
+
 #ifdef OCRGPU_STAMPS
 #define STAMP_LAUNCHES 8u // consecutive launches K0 .. K0+7 keep a per-workgroup table each
 #define STAMP_AT(j) d.dbg[16 + (size_t)(K - (u32)d.dbg[15]) * 8 * MAX_GRID + 8 * blockIdx.x + (j)]
@@ -648,7 +674,24 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     if (q_total > d.q_cap) q_total = d.q_cap;
     State N = P;
     N.r_total = r_total; N.q_total = q_total;
-    if (q_total > P.q_end) { N.mode = MODE_EVENTS; N.q_begin = P.q_end; N.q_end = q_total; }
+    // work split of a list of `n` entries: entries per workgroup (`per`) and workgroups with work (`part`), see below
+    auto split = [&](u32 n, u32 &per_, u32 &part_) {
+        per_ = (n + d.spread_wgs - 1) / d.spread_wgs;
+        if (per_ < 1) per_ = 1;
+        if (per_ > BLK) per_ = BLK;
+        if (per_ >= 16u) per_ = (per_ + 15u) & ~15u; // whole 16-entry (64-B) chunks, see the FIRE loop
+        part_ = (n + per_ - 1) / per_; if (part_ > gridDim.x) part_ = gridDim.x; // 0 for a forced empty level
+    };
+    const bool owed = P.b_end > P.b_begin; // the last launch fired a level and left its bodies to this one
+    bool flush_only = false;
+    if (owed && !(q_total > P.q_end) && P.allow_fire && r_total > P.r_end) {
+        // a WIDE level is about to fire behind owed bodies: its own bodies cannot wait for idle workgroups (there are few)
+        // and must not run beside the owed ones (they read their values), so this launch only pays the debt
+        u32 pr, pt; split(r_total - P.r_end, pr, pt);
+        flush_only = pt > gridDim.x / 2;
+    }
+    if (flush_only) { N.mode = MODE_EVENTS; N.q_begin = N.q_end = P.q_end; }
+    else if (q_total > P.q_end) { N.mode = MODE_EVENTS; N.q_begin = P.q_end; N.q_end = q_total; }
     else if (P.allow_fire && r_total > P.r_end) {
         if (P.allow_fire != 0xFFFFFFFFu) N.allow_fire = P.allow_fire - 1; // FIRE budget (distributed stepping: 1 level)
         N.mode = MODE_FIRE; N.level = P.level + 1; N.r_begin = P.r_end; N.r_end = r_total; N.n_levels = N.level + 1;
@@ -657,6 +700,19 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
         if (P.allow_fire != 0xFFFFFFFFu) N.allow_fire = P.allow_fire - 1;
         N.mode = MODE_FIRE; N.level = P.level + 1; N.r_begin = N.r_end = P.r_end; N.n_levels = N.level + 1;
     } else N.done = 1;
+    // Entries per workgroup per pass: spread a short list over the whole grid (a level of 255 EDTs with 255-waiter
+    // rows, or 512 pieces of a 1M-waiter row, must not land on one or two workgroups); BLK once the list is long.
+    // The spread stops at d.spread_wgs workgroups: every workgroup reserves its ready-log range with one atomic on
+    // the same counter, and same-address atomics serialise (~10 ns each: 2000 of them cost more than they save).
+    const u32 count = N.done ? 0u : (N.mode == MODE_FIRE) ? N.r_end - N.r_begin : N.q_end - N.q_begin;
+    u32 per, part; split(count, per, part);
+    // Bodies off the critical path: a FIRE launch on a single partition fans its level out and leaves the bodies (gather
+    // the depv datablocks, fold, store the result) to the NEXT launch, where the workgroups that have no work of their own
+    // run them (`deferred_bodies`).  Nothing on the dependence path waits for a body's value: consumers' bodies read it at
+    // the earliest two launches later.  A level is deferred when it leaves at least half the grid idle (a narrow level is
+    // most likely followed by another); a wide level runs its bodies itself, after a launch that only pays what is owed.
+    const bool defer = !N.done && N.mode == MODE_FIRE && d.n_loc <= 1 && part <= gridDim.x / 2;
+    N.b_begin = defer ? N.r_begin : 0u; N.b_end = defer ? N.r_end : 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         c->state[K & 1] = N;
         c->cnt_r[(K + 1) % 3].v = 0; c->cnt_q[(K + 1) % 3].v = 0;
@@ -665,21 +721,14 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             else atomicAdd(&c->err[ERR_LEVEL_OVERFLOW], 1u);
         }
     }
+    if (owed && part < gridDim.x) { // the idle workgroups of this launch run the bodies the last one left
+        if (blockIdx.x >= part) deferred_bodies(d, P.b_begin, P.b_end, blockIdx.x - part, gridDim.x - part);
+    }
     if (N.done) return;
     Step S;
     S.mode = N.mode; S.r_begin = N.r_begin; S.r_end = N.r_end; S.q_begin = N.q_begin; S.q_end = N.q_end;
     S.r_base = r_total; S.q_base = q_total; S.cnt_r = &c->cnt_r[K % 3].v; S.cnt_q = &c->cnt_q[K % 3].v;
     u64 n_edt_sat = 0, n_evt_sat = 0, n_fired = 0;
-    const u32 count = (S.mode == MODE_FIRE) ? S.r_end - S.r_begin : S.q_end - S.q_begin;
-    // Entries per workgroup per pass: spread a short list over the whole grid (a level of 255 EDTs with 255-waiter
-    // rows, or 512 pieces of a 1M-waiter row, must not land on one or two workgroups); BLK once the list is long.
-    // The spread stops at d.spread_wgs workgroups: every workgroup reserves its ready-log range with one atomic on
-    // the same counter, and same-address atomics serialise (~10 ns each: 2000 of them cost more than they save).
-    u32 per = (count + d.spread_wgs - 1) / d.spread_wgs;
-    if (per < 1) per = 1;
-    if (per > BLK) per = BLK;
-    if (per >= 16u) per = (per + 15u) & ~15u; // whole 16-entry (64-B) chunks, see the FIRE loop
-    u32 part = (count + per - 1) / per; if (part > gridDim.x) part = gridDim.x; // 0 for a forced empty level
     if (blockIdx.x >= part) return; // workgroups beyond the work leave at once
     STAMP(0);
 
@@ -724,8 +773,10 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) pw[k] = (u32)k < depc ? (sl[k] & 0x7FFFFFFFu) : 0u;
                 }
+                if (!defer) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
+                    for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
+                }
                 u32 ret = 0;
                 const u32 kind = OCRBODY_KIND(body);
                 if (kind == OCRBODY_HASH) ret = d.max_db + e + 1;
@@ -781,7 +832,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             else __syncthreads();
             STAMP(3);
-            if (mine && !body_first && OCRBODY_KIND(body) != OCRBODY_HOST) run_body(d, e, id, depc, sl, gb);
+            if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST) run_body(d, e, id, depc, sl, gb);
         }
     } else {
         // ---- queued satisfies: API calls, fired chained events, big-row pieces, direct EDT pre-slot satisfies ----
@@ -825,6 +876,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             else __syncthreads();
         }
     }
+    if (owed && part == gridDim.x) deferred_bodies(d, P.b_begin, P.b_end, blockIdx.x, gridDim.x); // no idle workgroup in this launch
     STAMP(4);
     // ---- statistics: wave shuffle -> LDS -> this workgroup's own slot (plain +=, no atomics) ----
     for (int o = 32; o > 0; o >>= 1) {
@@ -847,6 +899,10 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #endif
 }
 
+// A run that stopped on its launch budget pays the bodies it owes before the caller can look at values.
+__global__ __launch_bounds__(BLK) void k_owed_bodies(Dev d) { deferred_bodies(d, d.ctrl->b_begin, d.ctrl->b_end, blockIdx.x, gridDim.x); }
+__global__ void k_owed_clear(Dev d) { d.ctrl->b_begin = d.ctrl->b_end = 0; }
+
 // Start a run at launch index K0: seed state[(K0-1)&1] from the between-runs view (single thread).
 __global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) {
     Ctrl *c = d.ctrl;
@@ -858,7 +914,7 @@ __global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) {
     State P; memset(&P, 0, sizeof P);
     P.mode = MODE_EVENTS; P.level = c->level; P.r_begin = P.r_end = c->r_end; P.q_begin = P.q_end = c->q_begin;
     P.done = 0; P.allow_fire = allow_fire; P.r_total = c->r_tail; P.q_total = c->q_tail > d.q_cap ? d.q_cap : c->q_tail;
-    P.n_levels = c->n_levels; P.force_level = force_level;
+    P.n_levels = c->n_levels; P.force_level = force_level; P.b_begin = c->b_begin; P.b_end = c->b_end;
     c->state[(K0 - 1) & 1] = P;
     c->cnt_r[(K0 - 1) % 3].v = 0; c->cnt_q[(K0 - 1) % 3].v = 0;
     c->cnt_r[K0 % 3].v = 0; c->cnt_q[K0 % 3].v = 0;
@@ -869,6 +925,7 @@ __global__ void k_end(Dev d, u32 K) {
     Ctrl *c = d.ctrl;
     const State P = c->state[K & 1];
     c->level = P.level; c->r_end = P.r_end; c->n_levels = P.n_levels;
+    c->b_begin = P.b_begin; c->b_end = P.b_end; // bodies an interrupted run still owes (a finished run has flushed them)
     // a finished run made no appends after its totals were folded; an interrupted one (launch budget) did
     c->r_tail = P.r_total + (P.done ? 0u : c->cnt_r[K % 3].v);
     u32 qt = P.q_total + (P.done ? 0u : c->cnt_q[K % 3].v);
@@ -1711,6 +1768,10 @@ static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool ti
     e->launches_total += launched;
     e->launch_index = K - 1;
     k_end<<<1, 1, 0, e->stream>>>(d, K - 1);
+    if (!((State *)e->pinned_done)->done) { // stopped by the launch budget: the last level's bodies are still owed, and the caller may read values
+        k_owed_bodies<<<grid, BLK, 0, e->stream>>>(d);
+        k_owed_clear<<<1, 1, 0, e->stream>>>(d);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

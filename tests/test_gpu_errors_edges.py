@@ -146,3 +146,30 @@ def test_capacity_errors_are_reported_not_faulted():
     eng.add_dependence([0] * 4, g, [0] * 4, [MODE_RO] * 4)
     assert eng.resolve().fired == 4
     eng.close()
+
+
+def test_interrupted_resolve_leaves_no_body_owed():
+    """ocrgpu_resolve with a level budget stops between launches; bodies are run one launch behind their level, so a
+    stopped run must pay what it owes before it returns: every EDT that has a level has its value."""
+    import numpy as np
+    from ocr_amd import engine, opstream
+    from oracle import ref as O
+    s = opstream.layered_dag(3000, 10)
+    want = O.run_restatement(s)
+    p = engine.StreamProgram(s, flags=0).build()
+    calls = 0
+    while True:
+        st = p.eng.resolve(max_levels=1)
+        calls += 1
+        lv, val = p.eng.read_edts(0, s.n_edt)
+        got_lv, got_val = np.full(s.n_edt, -1, np.int32), np.zeros(s.n_edt, np.uint64)
+        eo = np.asarray(p.edt_order, dtype=np.int64)
+        got_lv[eo], got_val[eo] = lv, val
+        fired = got_lv >= 0
+        assert (got_lv[fired] == want.level[fired]).all()
+        assert (got_val[fired] == want.val[fired]).all(), f"call {calls}: values missing for fired EDTs"
+        if int(st.fired) == s.n_edt or calls > 100:
+            break
+    assert calls > 2 and int(st.fired) == s.n_edt
+    assert want.diff(p.result()) == []
+    p.eng.close()
