@@ -494,6 +494,7 @@ __device__ __forceinline__ bool latch_group(const Dev &d, bool is_latch, u32 x, 
 // ------------------------------------------------------------------------------------------------
 #define BLK 256
 #define MAX_GRID 2048
+#define HELPERS 256u         // fewest workgroups of a launch that run the bodies the last launch left
 #define BIG_ROW 2048u        // waiter rows longer than this are split into pieces fanned out by separate workgroups
 #define INVALID 0xFFFFFFFFu  // hole in the ready log (an edge that did not make its EDT ready)
 #define RF_DST_LATCH 2u      // waiter flag when the destination is an event: it is a LATCH (no state read needed)
@@ -722,7 +723,13 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
         }
     }
     if (owed && part < gridDim.x) { // the idle workgroups of this launch run the bodies the last one left
-        if (blockIdx.x >= part) deferred_bodies(d, P.b_begin, P.b_end, blockIdx.x - part, gridDim.x - part);
+        // one pass over the owed range when there are enough idle workgroups for it, never fewer than HELPERS of them
+        // (64 helpers looping over a 40 000-entry range take longer than the level beside them: 15.7 instead of 11.9 us);
+        // the rest of the idle workgroups leave at once
+        u32 n_help = (P.b_end - P.b_begin + BLK - 1) / BLK;
+        if (n_help < HELPERS) n_help = HELPERS;
+        if (n_help > gridDim.x - part) n_help = gridDim.x - part;
+        if (blockIdx.x >= part && blockIdx.x < part + n_help) deferred_bodies(d, P.b_begin, P.b_end, blockIdx.x - part, n_help);
     }
     if (N.done) return;
     Step S;
