@@ -578,7 +578,9 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
             }
         }
     }
-    __syncthreads(); // lds_base may be rewritten by the next chunk
+    // no barrier here: the next use of seg[] / lds_base comes after the barriers of the caller's next block scan, which no
+    // wave passes before every wave has left this function -- and a barrier's workgroup fence would hold each wave until its
+    // ready-log stores have landed
 }
 
 // A fired event whose row is longer than BIG_ROW is not expanded by one workgroup: queue one RF_PIECE record
@@ -665,7 +667,6 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     __shared__ Seg seg[BLK];
     __shared__ u32 wave_sums[4];
     __shared__ u32 lds_base;
-    __shared__ u64 red[12];
     Ctrl *c = d.ctrl;
     // ---- replicated phase decision (the scheduler's "get work", on the device, without a hand-over) ----
     const State P = c->state[(K - 1) & 1];
@@ -837,7 +838,6 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             __syncthreads();
             STAMP(2);
             if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
-            else __syncthreads();
             STAMP(3);
             if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST) run_body(d, e, id, depc, sl, gb);
         }
@@ -880,25 +880,20 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             seg[threadIdx.x] = sg;
             __syncthreads();
             if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
-            else __syncthreads();
         }
     }
     if (owed && part == gridDim.x) deferred_bodies(d, P.b_begin, P.b_end, blockIdx.x, gridDim.x); // no idle workgroup in this launch
     STAMP(4);
-    // ---- statistics: wave shuffle -> LDS -> this workgroup's own slot (plain +=, no atomics) ----
+    // ---- statistics: wave shuffle -> this workgroup's own slot, one fire-and-forget atomic per wave and counter.  No LDS
+    // stage and no barrier: a barrier's workgroup fence would make every wave wait here for its fan-out stores to land ----
     for (int o = 32; o > 0; o >>= 1) {
         n_edt_sat += __shfl_down(n_edt_sat, o); n_evt_sat += __shfl_down(n_evt_sat, o); n_fired += __shfl_down(n_fired, o);
     }
-    if ((threadIdx.x & 63) == 0) { u32 w = threadIdx.x >> 6; red[w * 3] = n_edt_sat; red[w * 3 + 1] = n_evt_sat; red[w * 3 + 2] = n_fired; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u64 a0 = red[0] + red[3] + red[6] + red[9], a1 = red[1] + red[4] + red[7] + red[10], a2 = red[2] + red[5] + red[8] + red[11];
-        if (a0 | a1 | a2) { // no-return atomics on this workgroup's own slots: fire-and-forget (a plain += is a load the exit waits for)
-            unsigned long long *bs = (unsigned long long *)(d.blk_stats + 4 * blockIdx.x);
-            if (a0) atomicAdd(bs, (unsigned long long)a0);
-            if (a1) atomicAdd(bs + 1, (unsigned long long)a1);
-            if (a2) atomicAdd(bs + 2, (unsigned long long)a2);
-        }
+    if ((threadIdx.x & 63) == 0 && (n_edt_sat | n_evt_sat | n_fired)) {
+        unsigned long long *bs = (unsigned long long *)(d.blk_stats + 4 * blockIdx.x);
+        if (n_edt_sat) atomicAdd(bs, (unsigned long long)n_edt_sat);
+        if (n_evt_sat) atomicAdd(bs + 1, (unsigned long long)n_evt_sat);
+        if (n_fired) atomicAdd(bs + 2, (unsigned long long)n_fired);
     }
     STAMP(5);
 #ifdef OCRGPU_STAMPS
