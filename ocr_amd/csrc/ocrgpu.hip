@@ -550,14 +550,16 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
             u64 w = d.waiters[seg[lo].row + (t - start)];
             u32 whi = (u32)(w >> 32);
             dst = (u32)w; flags = whi >> 28; slot = whi & 0x0FFFFFFFu; payload = seg[lo].payload;
-            if (flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, dst, slot, payload, flags); ++n_edt_sat; }
+            if (flags & RF_DST_EDT) ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, dst, slot, payload, flags);
             else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote(d, rd.guid, rd.slot, rd.flags, payload); }
             else {
-                to_evt = true; ++n_evt_sat;
+                to_evt = true;
                 if (flags & RF_DST_LATCH) { is_latch = true; kind = OCREVT_LATCH; }
                 else kind = (*evt_state(d, dst) >> 8) & 0xFF;
             }
         }
+        // statistics are wave totals (one ballot each), so the epilogue needs no cross-lane reduction
+        n_edt_sat += __popcll(__ballot(act && (flags & RF_DST_EDT))); n_evt_sat += __popcll(__ballot(to_evt));
         if (base == 0) { if (threadIdx.x == 0) *lds_base = rbase; __syncthreads(); rbase = *lds_base; }
         if (act) { if (rbase + t < d.fired_cap) d.fired[rbase + t] = ready ? dst : INVALID; else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u); }
         // event -> event dependences: run the destination's satisfy logic right here (commonSatisfyRegNode
@@ -767,6 +769,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             u32 e = INVALID;
             if (i < S.r_end) e = d.fired[i];
             const bool mine = e != INVALID;
+            bool epi = false;
             u32 body = 0, depc = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr; ulonglong2 gb[8];
             if (mine) {
                 const EdtLine L = d.edt[e]; // the one 64-B read that carries everything this EDT needs to fire
@@ -789,7 +792,6 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                 const u32 kind = OCRBODY_KIND(body);
                 if (kind == OCRBODY_HASH) ret = d.max_db + e + 1;
                 else if (kind == OCRBODY_FWD0) ret = pw[0];
-                ++n_fired;
                 // With other partitions around, a satisfy may carry this EDT's output DB away by value in this very
                 // launch, so the body runs first; on a single partition it runs after the fan-out (off the critical path).
                 const bool host_body = kind == OCRBODY_HOST; // taskExecute happens on the host (ocrgpu_pop_ready)
@@ -823,13 +825,14 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                         if (qi < d.q_cap) d.q[qi] = Rec{w, 0u, 0u, RF_ACQUIRE}; else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
                     });
                 if ((body & OCRBODY_F_OUTEVT) && !host_body) { // epilogue: satisfy the ONCE output event with the returned guid
-                    ++n_evt_sat;
+                    epi = true;
                     bool ok = true;
                     if (NANNY) ok = evt_satisfy_simple(d, x, OCREVT_ONCE, ret);
                     else d.edt[e].out_state = ST_DESTROYED | (OCREVT_ONCE << 8); // only its own EDT satisfies it
                     if (ok && !split_big_row(d, S, x, L.out_deg, ret)) { deg = L.out_deg; sg.row = L.out_row; sg.payload = ret; }
                 }
             }
+            n_fired += __popcll(__ballot(mine)); n_evt_sat += __popcll(__ballot(epi));
             STAMP(1);
             u32 total;
             u32 incl = block_inclusive_scan(deg, wave_sums, total);
@@ -848,15 +851,16 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             u32 i = threadIdx.x < per ? cb + threadIdx.x : S.q_end;
             bool act = i < S.q_end;
             Rec r = {0, 0, 0, 0};
-            bool ready = false, is_latch = false;
+            bool ready = false, is_latch = false, cnt_edt = false, cnt_evt = false;
             u32 kind = 0;
             if (act) {
                 r = d.q[i];
                 if (r.flags & RF_LAZYWALK) lazy_walk(d, r.dst, r.slot);
                 else if (LOCKABLE && (r.flags & RF_ACQUIRE)) ready = acq_walk(d, r.dst);
-                else if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, r.dst, r.slot, r.payload, r.flags); ++n_edt_sat; }
-                else if (!(r.flags & RF_FIRED)) { kind = (*evt_state(d, r.dst) >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); ++n_evt_sat; }
+                else if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, r.dst, r.slot, r.payload, r.flags); cnt_edt = true; }
+                else if (!(r.flags & RF_FIRED)) { kind = (*evt_state(d, r.dst) >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); cnt_evt = true; }
             }
+            n_edt_sat += __popcll(__ballot(cnt_edt)); n_evt_sat += __popcll(__ballot(cnt_evt));
             u32 ri = S.r_base + wave_append(S.cnt_r, ready);
             if (ready) d.fired[ri] = r.dst;
             bool fire = latch_group(d, is_latch, r.dst, r.slot);
@@ -884,12 +888,9 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     }
     if (owed && part == gridDim.x) deferred_bodies(d, P.b_begin, P.b_end, blockIdx.x, gridDim.x); // no idle workgroup in this launch
     STAMP(4);
-    // ---- statistics: wave shuffle -> this workgroup's own slot, one fire-and-forget atomic per wave and counter.  No LDS
-    // stage and no barrier: a barrier's workgroup fence would make every wave wait here for its fan-out stores to land ----
-    for (int o = 32; o > 0; o >>= 1) {
-        n_edt_sat += __shfl_down(n_edt_sat, o); n_evt_sat += __shfl_down(n_evt_sat, o); n_fired += __shfl_down(n_fired, o);
-    }
-    if ((threadIdx.x & 63) == 0 && (n_edt_sat | n_evt_sat | n_fired)) {
+    // ---- statistics: the counters are wave totals (ballots where they are counted) -> this workgroup's own slot, one
+    // fire-and-forget atomic per wave and counter.  No shuffles, no LDS stage and no barrier: a barrier's workgroup fence would make every wave wait here for its fan-out stores to land ----
+    if ((threadIdx.x & 63) == 0 && (n_edt_sat | n_evt_sat | n_fired)) { // wave totals already
         unsigned long long *bs = (unsigned long long *)(d.blk_stats + 4 * blockIdx.x);
         if (n_edt_sat) atomicAdd(bs, (unsigned long long)n_edt_sat);
         if (n_evt_sat) atomicAdd(bs + 1, (unsigned long long)n_evt_sat);
