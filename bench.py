@@ -271,7 +271,7 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     dist.destroy_process_group()
 
 
-def profiled_traffic(args, tag="r01f_config2"):
+def profiled_traffic(args, tag="r01g_config2"):
     """HBM bytes per k_step launch from the committed PMC passes (profiles/<tag>_pmc_summary.txt: FETCH_SIZE and
     WRITE_SIZE in KB, separate rocprofv3 --pmc runs of this same workload).  Counters cannot be read inside this
     process, so the figure is the profiled one; None for any other workload shape."""
