@@ -9,6 +9,12 @@ once, before the timed region, and is resident in HBM.  Prints ONE JSON line (se
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n-edt 10000000] [--width 10000]
                     [--no-cpu-baseline] [--no-parity]
+
+`--gpus N` with N > 1 and no RANK / WORLD_SIZE in the environment: this process starts N fresh rank processes
+itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE it imports torch or
+touches HIP, relays rank 0's JSON line and exits non-zero if any rank does -- the way the reference's
+ocrrun_x86-mpi launches its N policy domains on one node (ocr/build/x86-mpi/ocrrun_x86-mpi:77-108,147).
+Launched under torch.distributed.run (RANK / WORLD_SIZE set), it is one of the ranks and WORLD_SIZE must equal N.
 """
 import argparse
 import datetime
@@ -34,12 +40,18 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-sample-edts", type=int, default=4_000_000)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))          # the parent never initialises the GPU
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: n_gpus in the JSON line would not be what was asked for")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libocrgpu has no CPU path")
     local = local % torch.cuda.device_count()    # rehearsals put several ranks on one GPU (gloo backend)
@@ -149,6 +161,59 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def launch_ranks(n):
+    """Start n rank processes of this same command line (one per GPU) and relay rank 0's JSON line.  Nothing here
+    imports torch or calls HIP: the children are started with subprocess (fresh interpreters), never exec'd over a
+    process that has touched the GPU.  Returns the exit code for the parent (0 only if every rank exited 0 and rank 0
+    printed exactly one JSON line with n_gpus == n)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        codes = [None] * n
+        while any(c is None for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+            if any(c not in (None, 0) for c in codes):     # one rank failed: the others would wait for it in a collective
+                for i, p in enumerate(procs):
+                    if codes[i] is None:
+                        p.terminate()                       # the exact processes started above, nothing else
+                for i, p in enumerate(procs):
+                    if codes[i] is None:
+                        try:
+                            codes[i] = p.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            p.kill()
+                            codes[i] = p.wait()
+                break
+            time.sleep(0.1)
+        out0.seek(0)
+        text = out0.read()
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    for ln in text.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    if len(lines) != 1 or json.loads(lines[0]).get("n_gpus") != n:
+        print(f"bench.py: expected one JSON line with n_gpus={n} from rank 0, got {lines!r}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
 
 
 def collectives_selftest(torch, dist, local):
