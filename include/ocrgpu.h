@@ -43,7 +43,10 @@ enum {
     OCRGPU_ENOMEM = -12,   /* a capacity given at init is exhausted (OCR_ENOMEM)         */
     OCRGPU_EHIP = -5,      /* a HIP runtime call failed; ocrgpu_last_error() has the text */
     OCRGPU_ENODEV = -19,   /* no usable gfx950 device                                    */
-    OCRGPU_EFAULT = -14,   /* the device flagged a user-level error (see stats.err[])    */
+    OCRGPU_EFAULT = -14,   /* the device flagged a user-level error during this call (stats.err[] moved: a malformed op,
+                              a record dropped by a full queue, ...).  The call has done everything else it had to do and
+                              its outputs are filled; returned once per movement by ocrgpu_add_dependence,
+                              ocrgpu_event_satisfy_slot, ocrgpu_resolve and ocrgpu_step                                 */
     OCRGPU_ENOTSUP = -95
 };
 
@@ -65,7 +68,8 @@ enum {
 typedef struct {
     uint32_t max_edt;      /* EDTs this partition can hold                                   */
     uint32_t max_evt;      /* explicitly created events (output events come with the EDTs)   */
-    uint32_t max_db;       /* explicitly created datablocks (output DBs come with the EDTs)  */
+    uint32_t max_db;       /* explicitly created datablocks (output DBs come with the EDTs) + proxy copies of other
+                              partitions' datablocks that arriving records carry (one per such record, from the top) */
     uint32_t location;     /* LOCHOME id of this partition (== rank)                          */
     uint64_t max_slots;    /* sum of depc over all EDTs                                       */
     uint64_t max_edges;    /* waiter registrations (event -> EDT|event dependences), < 2^32   */
@@ -114,9 +118,13 @@ int ocrgpu_abi_version(void);
 int ocrgpu_guid_reserve(ocrgpu_engine_t *e, uint32_t kind, uint64_t n, uint64_t *guids_out, int where);
 /* registerGuid / hashtable put (:302, hashtable.c:498): vals must be non-zero */
 int ocrgpu_guid_put(ocrgpu_engine_t *e, uint64_t n, const uint64_t *guids, const uint64_t *vals, int where);
+/* hashtableConcBucketLockedTryPut (hashtable.c:527-554; labeled create with GUID_PROP_CHECK, labeled-guid.c): insert
+ * guids[i] -> vals[i] unless the guid is already in the table; held_out[i] = the value the table holds for it afterwards
+ * (== vals[i] when this call inserted it).  Safe for several elements of one batch naming the same guid: one wins. */
+int ocrgpu_guid_tryput(ocrgpu_engine_t *e, uint64_t n, const uint64_t *guids, const uint64_t *vals, uint64_t *held_out, int where);
 /* getVal (:394-406, hashtable.c:461): vals_out[i] = 0 when the guid does not resolve */
 int ocrgpu_guid_get(ocrgpu_engine_t *e, uint64_t n, const uint64_t *guids, uint64_t *vals_out, int where);
-/* releaseGuid / unregisterGuid (:527-572, hashtable.c:527) */
+/* releaseGuid / unregisterGuid (:527-572, hashtable.c:527): the slot becomes a tombstone that a later put takes over */
 int ocrgpu_guid_remove(ocrgpu_engine_t *e, uint64_t n, const uint64_t *guids, int where);
 
 /* ---- object creation (replace newEventHc hc-event.c:1558-1765, newTaskHc hc-task.c:871-1136,

@@ -51,6 +51,19 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_
 #define PEND_LAZY 0x40000000u  // EdtLine.pending: a COUNTED event sits on a pre-slot the frontier has not reached -> track the frontier
 #define PEND_ACQ 0x20000000u   // EdtLine.pending: Lockable datablocks -- the EDT acquires its datablocks before it is scheduled
 #define PEND_MASK 0x1FFFFFFFu
+// EdtLine.pending of an EDT whose pre-slots live in its line (depc <= 6): bits 0..7 = unsatisfied pre-slots, bit 8+k = pre-slot k
+// has been satisfied.  The satisfier's ONE atomic adds (1 << (8+k)) - 1: it counts the slot down and marks it, so the frontier
+// walk of lazily registered COUNTED events (hc-task.c:1286-1338) can tell a satisfied pre-slot whose payload word was written
+// at registration (RF_PREFILLED: the satisfy stores nothing) from an unsatisfied one.  EDTs with more pre-slots keep a plain
+// count in bits 0..28 and mark the (always stored, never pre-filled) overflow slot words.
+#define PEND_INL_CNT 0xFFu
+#define PEND_INL_BIT(k) (0x100u << (k))
+// Fire info of an EDT, kept beside every waiter record that names it and handed on through the ready log, so that the FIRE
+// pass can start the EDT's fan-out without reading its line: {out_row, fi}; fi = FI_FAST | FI_OUTEVT | FI_OUTDB | out_deg.
+#define FI_FAST 0x80000000u   // the entry is valid: built-in HASH / NOP body, no script, row no longer than BIG_ROW
+#define FI_OUTDB 0x40000000u  // the body returns its own output datablock (HASH); else NULL_GUID (NOP)
+#define FI_OUTEVT 0x20000000u // the EDT has a ONCE output event (else out_deg = 0)
+#define FI_DEG 0x0000FFFFu
 #define LAZY_FRONT 0xFFFFFFFFu // lazy_tab key slot of an EDT's frontier word
 #define CNT_SAT (1ull << 63)   // counted[]: [satisfied:1 | registrations left:31 | lazy registrations not yet made:32]
 #define BODY_F_SCRIPT 0x10000u // internal: EDT has a script
@@ -113,7 +126,9 @@ struct alignas(128) Ctrl {
     u32 level, r_end, q_begin, pad0, n_levels, b_begin, b_end, pad1[25];
     u32 r_tail; u32 pad2[31];   // atomics (own cache lines)
     u32 q_tail; u32 pad3[31];
-    u32 log_tail; u32 rdst_tail; u32 chan_count, chan_wait_used, chan_sat_used; u32 pad4[27];
+    u32 log_tail; u32 rdst_tail; u32 chan_count, chan_wait_used, chan_sat_used;
+    u32 proxy_used;             // proxy datablocks (copies of other partitions' DBs that records carried in) taken from the TOP of db[0,max_db)
+    u32 pad4[26];
     u32 err[8];
     DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB only (else null): lock word + waiter lists per datablock; access mode per
                                           // EDT pre-slot.  Kept here, not in Dev: the hot kernel's argument block stays as small as it was
@@ -135,12 +150,14 @@ struct Dev {
                                 // CHANNEL events: satisfies so far << 32 | registrations so far
     ChanRec *chan; u32 *chan_sat; u32 chan_sat_cap; // CHANNEL events: evt[x].val = index into chan[]
     ulonglong2 *lazy_tab; u64 lazy_mask; // (EDT, pre-slot) -> COUNTED event waiting for the frontier; (EDT, LAZY_FRONT) -> frontier
-    u64 *waiters;               // CSR payload: lo = dst ; hi = flags<<28 | (pre-slot k of the EDT | latch slot)
+    ulonglong2 *waiters;        // CSR payload, 16 B: x.lo = dst ; x.hi = flags<<28 | (pre-slot k of the EDT | latch slot);
+                                // y = fire info of an EDT destination {out_row, fi} (0 = none: the FIRE pass reads the EDT's line)
     u32 *log_src; u64 *log_rec; // registration log the CSR is built from
     // datablocks (explicit [0,max_db) then the output DB of EDT e at max_db+e): {value, tag}
     ulonglong2 *db;
     // work lists
     u32 *fired;                 // fired/ready log, grouped by level
+    u64 *fired_aux;             // beside every valid entry of `fired`: the EDT's fire info {out_row, fi} or 0
     u32 *level_start;           // level_start[L] = offset in `fired`
     Rec *q;                     // satisfy-record log
     u64 *blk_stats;             // [MAX_GRID][4] per-workgroup counters (no atomics): edt_sat, evt_sat, fired
@@ -157,6 +174,7 @@ struct Dev {
 };
 
 #define TOMB (~0ULL)
+#define GRESV (~0ULL - 1)   // slot claimed, value not yet published (== UNINITIALIZED_GUID, never a key)
 
 // event accessors: explicit events and EDT output events share one index space
 __device__ __forceinline__ u32 *evt_state(const Dev &d, u32 x) { return x < d.max_evt ? &d.evt[x].state_kind : &d.edt[x - d.max_evt].out_state; }
@@ -167,13 +185,54 @@ __device__ __forceinline__ u32 *evt_row(const Dev &d, u32 x) { return x < d.max_
 __device__ __forceinline__ u64 mkguid(u32 loc, u32 kind, u64 counter) { return ((u64)loc << 54) | ((u64)kind << 49) | counter; }
 __device__ __forceinline__ u32 ghash(const Dev &d, u64 g) { return (u32)((g * 0x9E3779B97F4A7C15ULL) >> d.gshift); }
 
+// Open addressing, linear probing, 16-B slots {guid, value}; 0 = empty, TOMB = removed, GRESV = being written.
+// A slot is published value first, key last (value store, agent fence, key exchange), so a reader that matches the key in its
+// one 16-B load holds the value that belongs to it; remove only turns the key into TOMB.  hashtableConcBucketLockedPut
+// (hashtable.c:498-525): a put takes over the first tombstone it passed once it knows the key is not further down the chain
+// (removes give capacity back); a key already present gets the new value.  Concurrent puts of ONE key in one batch may
+// leave two entries (guids are unique; the reference's put does not check either): callers that race on a key use tryput.
+__device__ __forceinline__ void gtab_publish(const Dev &d, u64 h, u64 key, u64 val) {
+    d.gtab[h].y = val;
+    __threadfence();
+    atomicExch((unsigned long long *)&d.gtab[h].x, (unsigned long long)key);
+}
 __device__ void gtab_put(const Dev &d, u64 key, u64 val) {
-    u64 h = ghash(d, key);
-    for (u64 probe = 0; probe <= d.gmask; ++probe, h = (h + 1) & d.gmask) {
-        u64 old = atomicCAS((unsigned long long *)&d.gtab[h].x, 0ULL, (unsigned long long)key);
-        if (old == 0ULL || old == key) { d.gtab[h].y = val; return; }
+    for (int attempt = 0; attempt < 1024; ++attempt) { // a lost claim means another put made progress: walk the chain again
+        u64 h = ghash(d, key), tomb = ~0ULL;
+        bool lost = false;
+        for (u64 probe = 0; probe <= d.gmask; ++probe, h = (h + 1) & d.gmask) {
+            const u64 k = atomicAdd((unsigned long long *)&d.gtab[h].x, 0ULL);
+            if (k == key) { d.gtab[h].y = val; return; }
+            if (k == TOMB && tomb == ~0ULL) tomb = h;
+            if (k != 0ULL) continue;
+            // end of the chain: the key is not in the table
+            if (tomb != ~0ULL) break;
+            if (atomicCAS((unsigned long long *)&d.gtab[h].x, 0ULL, GRESV) == 0ULL) { gtab_publish(d, h, key, val); return; }
+            lost = true; break;
+        }
+        if (tomb != ~0ULL) {
+            if (atomicCAS((unsigned long long *)&d.gtab[tomb].x, TOMB, GRESV) == TOMB) { gtab_publish(d, tomb, key, val); return; }
+            lost = true;
+        }
+        if (!lost) break; // neither an empty slot nor a tombstone on the whole walk: the table is full
     }
     atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+}
+// hashtableConcBucketLockedTryPut (hashtable.c:527-554 region, :385-420 for the CAS variant): insert unless the key is there;
+// returns the value the table holds for the key afterwards.  Linearisable among concurrent tryputs of one key: every
+// contender walks the same chain and claims the first EMPTY slot only (no tombstone reuse on this path), and a slot found
+// reserved is looked at again until its owner has published it.
+__device__ u64 gtab_tryput(const Dev &d, u64 key, u64 val) {
+    u64 h = ghash(d, key);
+    for (u64 probe = 0; probe <= d.gmask;) {
+        const u64 k = atomicCAS((unsigned long long *)&d.gtab[h].x, 0ULL, GRESV);
+        if (k == 0ULL) { gtab_publish(d, h, key, val); return val; }
+        if (k == GRESV) continue;                      // its owner publishes within a few instructions: look again
+        if (k == key) return atomicAdd((unsigned long long *)&d.gtab[h].y, 0ULL);
+        ++probe; h = (h + 1) & d.gmask;
+    }
+    atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+    return 0;
 }
 __device__ u64 gtab_get(const Dev &d, u64 key) {
     if (key == 0ULL || key >= TOMB - 1) return 0;
@@ -185,12 +244,22 @@ __device__ u64 gtab_get(const Dev &d, u64 key) {
     }
     return 0;
 }
+// hashtableConcBucketLockedRemove (hashtable.c:556-575).  The slot becomes a tombstone a later put takes over -- or, when it
+// ends its run (the next slot is empty), an empty slot again together with the tombstones right before it, so that chains
+// shrink back and tryput (which only claims empty slots) keeps finding room in a table that has seen many removes.  Removes
+// run in batches of their own (no put or get in the same launch): within such a launch "the next slot is empty" stays true
+// once seen, which is what makes emptying a slot safe (no live key's probe path runs over it).
 __device__ void gtab_remove(const Dev &d, u64 key) {
     u64 h = ghash(d, key);
     for (u64 probe = 0; probe <= d.gmask; ++probe, h = (h + 1) & d.gmask) {
-        u64 k = d.gtab[h].x;
-        if (k == key) { d.gtab[h].y = 0; d.gtab[h].x = TOMB; return; }
+        const u64 k = d.gtab[h].x;
         if (k == 0ULL) return;
+        if (k != key) continue;
+        if (atomicAdd((unsigned long long *)&d.gtab[(h + 1) & d.gmask].x, 0ULL) != 0ULL) { atomicExch((unsigned long long *)&d.gtab[h].x, TOMB); return; }
+        atomicExch((unsigned long long *)&d.gtab[h].x, 0ULL);
+        for (u64 b = (h - 1) & d.gmask, n = 0; n < 256; b = (b - 1) & d.gmask, ++n)
+            if (atomicCAS((unsigned long long *)&d.gtab[b].x, TOMB, 0ULL) != TOMB) break;
+        return;
     }
 }
 // resolve an engine-made guid to its object index, honouring lazy deletion of dead events
@@ -241,19 +310,26 @@ __device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, const Step &S, u3
     } else if (!(flags & RF_PREFILLED)) {
         *sp = word | SLOT_MARK;
     }
-    const u32 old = atomicSub(&L->pending, 1u);
+    const bool inl = (flags & RF_INLINE) != 0;
+    const u32 old = atomicAdd(&L->pending, inl ? PEND_INL_BIT(slot) - 1u : 0xFFFFFFFFu); // count down (+ mark, inline pre-slots)
+    const u32 left = old & (inl ? PEND_INL_CNT : PEND_MASK);
     if (old & PEND_LAZY) { // rare: this EDT's frontier is tracked (COUNTED accounting); the walk runs in the next EVENTS phase
         const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
         if (qi < d.q_cap) d.q[qi] = Rec{edt, 0u, slot, RF_LAZYWALK}; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
     }
     if (LOCKABLE) { // Lockable datablocks (every EDT carries PEND_ACQ): all satisfied -> acquire first (taskAllDepvSatisfied)
-        if ((old & PEND_MASK) == 1u) {
+        if (left == 1u) {
             const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
             if (qi < d.q_cap) d.q[qi] = Rec{edt, 0u, 0u, RF_ACQUIRE}; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
         }
         return false;
     }
-    return (old & PEND_MASK) == 1u;
+    return left == 1u;
+}
+// has pre-slot f of this EDT been satisfied?  (frontier walks; reads through returning atomics: other CUs write these words)
+__device__ __forceinline__ bool slot_satisfied(EdtLine *L, u32 *sl, u32 depc, u32 f) {
+    if (atomicOr(&sl[f], 0u) & SLOT_MARK) return true;
+    return depc <= INLINE_SLOTS && (atomicOr(&L->pending, 0u) & PEND_INL_BIT(f)) != 0;
 }
 
 // ---- COUNTED accounting + lazy frontier registration --------------------------------------------------------
@@ -338,7 +414,7 @@ __device__ __forceinline__ void lazy_walk(const Dev &d, u32 edt, u32 slot) {
     if (!F) return;
     u64 f = atomicAdd((unsigned long long *)F, 0ull);
     while (f < depc) {
-        if (!(atomicOr(&sl[f], 0u) & SLOT_MARK)) break;
+        if (!slot_satisfied(L, sl, depc, (u32)f)) break;
         if (atomicCAS((unsigned long long *)F, (unsigned long long)f, (unsigned long long)(f + 1)) == f && f + 1 < depc) {
             const u64 *xv = lazy_find(d, lazy_key(edt, (u32)f + 1));
             if (xv) lazy_reached(d, *xv);
@@ -542,12 +618,13 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         u32 t = base + threadIdx.x;
         bool act = t < total;
         bool ready = false, to_evt = false, is_latch = false;
-        u32 dst = 0, slot = 0, payload = 0, flags = 0, kind = 0;
+        u32 dst = 0, slot = 0, payload = 0, flags = 0, kind = 0; u64 finfo = 0;
         if (act) {
             u32 lo = 0, hi = nseg - 1; // first segment with end_off > t
             while (lo < hi) { u32 mid = (lo + hi) >> 1; if (seg[mid].end_off > t) hi = mid; else lo = mid + 1; }
             u32 start = lo ? seg[lo - 1].end_off : 0;
-            u64 w = d.waiters[seg[lo].row + (t - start)];
+            const ulonglong2 w2 = d.waiters[seg[lo].row + (t - start)]; // one 16-B load: the edge and its destination's fire info
+            const u64 w = w2.x; finfo = w2.y;
             u32 whi = (u32)(w >> 32);
             dst = (u32)w; flags = whi >> 28; slot = whi & 0x0FFFFFFFu; payload = seg[lo].payload;
             if (flags & RF_DST_EDT) ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, dst, slot, payload, flags);
@@ -561,7 +638,10 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         // statistics are wave totals (one ballot each), so the epilogue needs no cross-lane reduction
         n_edt_sat += __popcll(__ballot(act && (flags & RF_DST_EDT))); n_evt_sat += __popcll(__ballot(to_evt));
         if (base == 0) { if (threadIdx.x == 0) *lds_base = rbase; __syncthreads(); rbase = *lds_base; }
-        if (act) { if (rbase + t < d.fired_cap) d.fired[rbase + t] = ready ? dst : INVALID; else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u); }
+        if (act) {
+            if (rbase + t < d.fired_cap) { d.fired[rbase + t] = ready ? dst : INVALID; if (ready) d.fired_aux[rbase + t] = finfo; }
+            else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
+        }
         // event -> event dependences: run the destination's satisfy logic right here (commonSatisfyRegNode
         // recursing into processMessage, hc-event.c:335-367); only an event that FIRES costs a queue record
         if (__ballot(to_evt)) {
@@ -766,12 +846,24 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             // Critical path per level: ready-log entry -> the EDT's 64-B line -> waiter row -> atomicSub -> log store.
             // The body's gathers (the DBs named by the pre-slot words, which sit in the same line) are issued
             // BEFORE the fan-out and consumed after it, so they ride under it.
-            u32 e = INVALID;
-            if (i < S.r_end) e = d.fired[i];
+            u32 e = INVALID; u64 aux = 0;
+            if (i < S.r_end) { e = d.fired[i]; aux = d.fired_aux[i]; } // both coalesced; aux of a hole is never looked at
             const bool mine = e != INVALID;
             bool epi = false;
             u32 body = 0, depc = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr; ulonglong2 gb[8];
-            if (mine) {
+            // Fast path (plain single-partition run, bodies deferred): the ready-log entry carries the EDT's fire info, handed
+            // on by the satisfier from the waiter record it had just read, so the fan-out starts from the entry itself and the
+            // critical path of a level is entry -> waiter row -> atomic -> entry: the EDT's line is not read here at all (the
+            // deferred body reads it one launch later, off the path).  The output event is marked destroyed with a blind store.
+            const u32 fi = (u32)(aux >> 32);
+            const bool fast = !NANNY && !LOCKABLE && defer && mine && (fi & FI_FAST);
+            if (fast) {
+                if (fi & FI_OUTEVT) {
+                    epi = true;
+                    d.edt[e].out_state = ST_DESTROYED | (OCREVT_ONCE << 8); // satisfyEventHcOnce: fires, then destroys itself
+                    deg = fi & FI_DEG; sg.row = (u32)aux; sg.payload = (fi & FI_OUTDB) ? d.max_db + e + 1 : 0u;
+                }
+            } else if (mine) {
                 const EdtLine L = d.edt[e]; // the one 64-B read that carries everything this EDT needs to fire
                 body = L.body; depc = L.depc; id = L.param0;
                 const u32 x = d.max_evt + e;
@@ -842,7 +934,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             STAMP(2);
             if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             STAMP(3);
-            if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST) run_body(d, e, id, depc, sl, gb);
+            if (mine && !fast && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST) run_body(d, e, id, depc, sl, gb);
         }
     } else {
         // ---- queued satisfies: API calls, fired chained events, big-row pieces, direct EDT pre-slot satisfies ----
@@ -862,7 +954,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             }
             n_edt_sat += __popcll(__ballot(cnt_edt)); n_evt_sat += __popcll(__ballot(cnt_evt));
             u32 ri = S.r_base + wave_append(S.cnt_r, ready);
-            if (ready) d.fired[ri] = r.dst;
+            if (ready) { d.fired[ri] = r.dst; d.fired_aux[ri] = 0ull; }
             bool fire = latch_group(d, is_latch, r.dst, r.slot);
             if (act && (r.flags & RF_CHANGEN)) { deg = 1; sg.row = r.slot; sg.payload = r.payload; } // a CHANNEL pairing made in a fan-out
             else if (act && (r.flags & RF_FIRED)) fire = true;
@@ -1023,7 +1115,7 @@ __global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, con
         gtab_put(d, gd, (u64)(d.max_db + e) + 1);
         if (outdb_out) outdb_out[i] = gd;
     }
-    if (dc == 0) { u32 ri = atomicAdd(&d.ctrl->r_tail, 1u); d.fired[ri] = e; } // fires at creation (hc-task.c:1129-1134)
+    if (dc == 0) { u32 ri = atomicAdd(&d.ctrl->r_tail, 1u); d.fired[ri] = e; d.fired_aux[ri] = 0ull; } // fires at creation (hc-task.c:1129-1134)
 }
 
 __device__ __forceinline__ void q_push(const Dev &d, Rec r) {
@@ -1060,7 +1152,7 @@ __device__ __forceinline__ bool chan_register(const Dev &d, u32 x, u64 waiter, u
     const u32 k = (u32)old, ns = (u32)(old >> 32);
     if (k < ns) { payload = d.chan_sat[c.sat_base + k % c.cap]; return true; }
     if (k - ns >= c.cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return false; } // more than maxGen waiters in line (ASSERT :2005)
-    d.waiters[c.wait_base + k % c.cap] = waiter;
+    d.waiters[c.wait_base + k % c.cap] = make_ulonglong2(waiter, 0ull);
     return false;
 }
 
@@ -1130,9 +1222,9 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
         // COUNTED source on a pre-slot the EDT's frontier has not reached (an earlier pre-slot is not satisfied yet):
         // the data path registers now, the COUNT waits for the frontier (registerSignalerTaskHc hc-task.c:1391-1405)
         EdtLine *L = &d.edt[didx];
-        const u32 *sl = (dflag & RF_INLINE) ? L->slot : d.slots + L->slot[0];
+        u32 *sl = (dflag & RF_INLINE) ? L->slot : d.slots + L->slot[0];
         u32 f = 0;
-        while (f < slot[i] && (sl[f] & SLOT_MARK)) ++f;
+        while (f < slot[i] && slot_satisfied(L, sl, L->depc, f)) ++f;
         if (f < slot[i]) {
             lazy = true;
             atomicOr(&L->pending, PEND_LAZY);
@@ -1161,7 +1253,8 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
             if (bk == OCRBODY_HASH) { known = true; word = d.max_db + se + 1; }
             else if (bk == OCRBODY_NOP) known = true;
         }
-        if (known) { pre = RF_PREFILLED; *((dflag & RF_INLINE) ? &d.edt[didx].slot[dslot] : &d.slots[(size_t)d.edt[didx].slot[0] + dslot]) = word; }
+        // inline pre-slots only: their satisfied mark rides in the pending word; an overflow word is marked by the satisfy's store
+        if (known && (dflag & RF_INLINE)) { pre = RF_PREFILLED; d.edt[didx].slot[dslot] = word; }
     }
     u32 li = atomicAdd(&d.ctrl->log_tail, 1u);
     if ((u64)li + d.ctrl->chan_wait_used >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // waiters[] top end = CHANNEL rings
@@ -1265,7 +1358,8 @@ __global__ void k_script_merge_latch(Dev d, u64 n, const u32 *begin, const u32 *
 
 // Apply satisfies received from other partitions: resolve the guid in OUR table, clone the DB into a proxy
 // entry, and queue an ordinary record (the next EVENTS phase does the rest).
-__device__ void apply_record(const Dev &d, const SendRec &r, u32 proxy) {
+// `db_floor` = explicit datablocks created so far (host mirror): proxies grow down from max_db and must not reach them
+__device__ void apply_record(const Dev &d, const SendRec &r, u32 db_floor) {
     if (r.flags & XF_DESTROY) {
         u64 v = (OCRGPU_GUID_LOCATION(r.guid) == d.location && is_event_kind(OCRGPU_GUID_KIND(r.guid))) ? gtab_get(d, r.guid) : 0;
         if (!v) { bad_op(d); return; }
@@ -1284,9 +1378,9 @@ __device__ void apply_record(const Dev &d, const SendRec &r, u32 proxy) {
     if (r.flags & XF_LAZYREG) { // same decision as k_add_dep makes for a local COUNTED source
         if (!(dflag & RF_DST_EDT)) { bad_op(d); return; }
         EdtLine *L = &d.edt[didx];
-        const u32 *sl = (dflag & RF_INLINE) ? L->slot : d.slots + L->slot[0];
+        u32 *sl = (dflag & RF_INLINE) ? L->slot : d.slots + L->slot[0];
         u32 f = 0;
-        while (f < r.slot && (sl[f] & SLOT_MARK)) ++f;
+        while (f < r.slot && slot_satisfied(L, sl, L->depc, f)) ++f;
         if (f < r.slot) {
             atomicOr(&L->pending, PEND_LAZY);
             lazy_insert(d, lazy_key(didx, LAZY_FRONT), f);
@@ -1295,21 +1389,26 @@ __device__ void apply_record(const Dev &d, const SendRec &r, u32 proxy) {
         return;
     }
     u32 pay = 0;
-    if (r.flags & XF_HAS_DB) { d.db[proxy] = make_ulonglong2(r.value, r.tag); pay = proxy + 1; }
+    if (r.flags & XF_HAS_DB) { // only a record that carries a datablock takes a proxy entry
+        const u32 pi = atomicAdd(&d.ctrl->proxy_used, 1u);
+        if ((u64)pi + 1 + db_floor > d.max_db) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+        const u32 proxy = d.max_db - 1u - pi;
+        d.db[proxy] = make_ulonglong2(r.value, r.tag); pay = proxy + 1;
+    }
     if ((dflag & RF_DST_EDT) && (r.flags & XF_MODE_NULL)) dflag |= RF_MODE_NULL;
     q_push(d, Rec{didx, pay, dslot, dflag});
 }
-__global__ void k_exchange_apply(Dev d, u64 n, const SendRec *recs, u32 proxy_base) {
+__global__ void k_exchange_apply(Dev d, u64 n, const SendRec *recs, u32 db_floor) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) apply_record(d, recs[i], proxy_base + (u32)i);
+    if (i < n) apply_record(d, recs[i], db_floor);
 }
 // one receive buffer of n_src regions of `stride` records (an equal-split all-to-all): region s holds cnt[s] records,
 // cnt[n_src + s] = records in the regions before it
-__global__ void k_exchange_apply_strided(Dev d, u32 n_src, u64 stride, u32 max_cnt, const u32 *cnt, const SendRec *recs, u32 proxy_base) {
+__global__ void k_exchange_apply_strided(Dev d, u32 n_src, u64 stride, u32 max_cnt, const u32 *cnt, const SendRec *recs, u32 db_floor) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     u32 s = (u32)(i / max_cnt), k = (u32)(i % max_cnt);
     if (s >= n_src || k >= cnt[s]) return;
-    apply_record(d, recs[(u64)s * stride + k], proxy_base + cnt[n_src + s] + k);
+    apply_record(d, recs[(u64)s * stride + k], db_floor);
 }
 // OCRGPU_STEP_WRITE_HEADERS: {records for this destination, my activity} in the last record slot of every region
 __global__ void k_exchange_headers(Dev d, u32 K) {
@@ -1373,8 +1472,25 @@ __global__ void k_csr_fill(Dev d, u32 *cursor) {
     u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         u32 x = d.log_src[i];
-        if ((*evt_state(d, x) & 0xFF) == ST_LIVE) d.waiters[atomicAdd(&cursor[x], 1u)] = d.log_rec[i];
+        if ((*evt_state(d, x) & 0xFF) != ST_LIVE) continue;
+        const u64 rec = d.log_rec[i];
+        u64 finfo = 0;
+        if (((u32)(rec >> 32) >> 28) & RF_DST_EDT) { // the destination's own fan-out, known now that every row has its place
+            const EdtLine *L = &d.edt[(u32)rec];
+            const u32 body = L->body, kind = OCRBODY_KIND(body);
+            if ((kind == OCRBODY_HASH || kind == OCRBODY_NOP) && !(body & BODY_F_SCRIPT)) {
+                if (!(body & OCRBODY_F_OUTEVT)) finfo = (u64)FI_FAST << 32;
+                else if (L->out_deg <= BIG_ROW)
+                    finfo = ((u64)(FI_FAST | FI_OUTEVT | (kind == OCRBODY_HASH ? FI_OUTDB : 0u) | L->out_deg) << 32) | L->out_row;
+            }
+        }
+        d.waiters[atomicAdd(&cursor[x], 1u)] = make_ulonglong2(rec, finfo);
     }
+}
+// a re-seal moved the rows: ready-log entries waiting to fire forget the fire info they carry (the FIRE pass reads the line)
+__global__ void k_ready_aux_clear(Dev d) {
+    const u32 b = d.ctrl->r_end, n = d.ctrl->r_tail;
+    for (u32 i = b + blockIdx.x * blockDim.x + threadIdx.x; i < n && i < d.fired_cap; i += gridDim.x * blockDim.x) d.fired_aux[i] = 0ull;
 }
 
 // ---- exclusive scan (u32), 1024 elements per workgroup, recursive over the partials -------------------
@@ -1405,6 +1521,11 @@ __global__ void k_guid_reserve(Dev d, u32 kind, u64 n, u64 first_counter, u64 *o
 __global__ void k_guid_put(Dev d, u64 n, const u64 *g, const u64 *v) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) { if (g[i] == 0 || g[i] >= TOMB - 1 || v[i] == 0) bad_op(d); else gtab_put(d, g[i], v[i]); }
+}
+__global__ void k_guid_tryput(Dev d, u64 n, const u64 *g, const u64 *v, u64 *held) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (g[i] == 0 || g[i] >= TOMB - 1 || v[i] == 0) { bad_op(d); held[i] = 0; } else held[i] = gtab_tryput(d, g[i], v[i]);
 }
 __global__ void k_guid_get(Dev d, u64 n, const u64 *g, u64 *v) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -1472,20 +1593,23 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); return OCRGPU_EHIP; } } while (0)
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
-struct Snapshot { DbLock *dbl; EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; u64 *chan_wait; u32 *chan_sat; u32 chan_wait_used, chan_sat_used; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries; bool valid; };
+struct Snapshot { DbLock *dbl; EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; ulonglong2 *chan_wait; u32 *chan_sat; u32 chan_wait_used, chan_sat_used; u32 *fired; u64 *fired_aux; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries;
+                  u64 edges_upper, seal_epoch, err_seen; bool valid; };
 static void snap_free(Snapshot &s) {
     if (s.dbl) (void)hipFree(s.dbl);
     s.dbl = nullptr;
-    (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.counted); (void)hipFree(s.lazy_tab); (void)hipFree(s.slots); (void)hipFree(s.chan_wait); (void)hipFree(s.chan_sat); (void)hipFree(s.fired); (void)hipFree(s.ctrl);
+    (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.counted); (void)hipFree(s.lazy_tab); (void)hipFree(s.slots); (void)hipFree(s.chan_wait); (void)hipFree(s.chan_sat); (void)hipFree(s.fired); (void)hipFree(s.fired_aux); (void)hipFree(s.ctrl);
     s.valid = false;
 }
 
+#define PIN_ERR 33020u // u32 index into pinned_done of the 8 error counters the last poll brought back
 struct ocrgpu_engine {
+    u64 err_seen;  // sum of Ctrl.err[] the caller has been told about (OCRGPU_EFAULT)
     int device; hipStream_t stream; ocrgpu_config_t cfg; Dev d;
     std::vector<void *> allocs;
     // host mirrors
     u32 n_edt, n_evt, n_db; u64 n_slots, n_script, script_cap, lazy_cap; u64 counter; u64 edges_upper;
-    bool csr_dirty; u32 q_cap;
+    bool csr_dirty; u32 q_cap; u64 seal_epoch;
     // staging
     char *stage_dev; size_t stage_dev_cap, stage_dev_off; char *stage_host; size_t stage_host_cap;
     u32 *tmp_a, *tmp_b, *tmp_c; // scan temporaries sized for max(max_edt, n_evt_total)
@@ -1578,7 +1702,8 @@ static int scan_u32(ocrgpu_engine *e, const u32 *in, u32 *out, u64 n, u32 add0, 
     return 0;
 }
 
-extern "C" int ocrgpu_abi_version(void) { return 1; }
+static int scratch_setup(int device);
+extern "C" int ocrgpu_abi_version(void) { return 2; }
 extern "C" const char *ocrgpu_last_error(void) { return g_err; }
 
 extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_config_t *cfg) {
@@ -1590,10 +1715,11 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     if (cfg->max_edges >= (1ull << 32) || cfg->max_slots >= (1ull << 31)) FAIL(OCRGPU_EINVAL, "max_edges < 2^32 and max_slots < 2^31 per partition");
     if (cfg->location >= 1024) FAIL(OCRGPU_EINVAL, "location must fit GUID_PROVIDER_LOCID_SIZE=10 bits");
     HIPCHK(hipSetDevice(device));
+    { int sr = scratch_setup(device); if (sr) return sr; } // this GPU's address of the static scratch array (ocrgpu_pop_ready_noalloc)
     ocrgpu_engine *e = new ocrgpu_engine();
-    e->device = device; e->stream = 0; e->cfg = *cfg;
+    e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
-    e->csr_dirty = false; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
+    e->csr_dirty = false; e->seal_epoch = 0; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->snap.dbl = nullptr; e->have_events = false;
     e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr; e->dbl = nullptr; e->acq_mode = nullptr;
     e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->pop_cursor = e->snap_pop_cursor = 0; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
@@ -1603,7 +1729,9 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     d.max_slots = cfg->max_slots ? cfg->max_slots : 1; d.max_edges = cfg->max_edges ? cfg->max_edges : 1;
     d.max_levels = cfg->max_levels ? cfg->max_levels : (1u << 20);
     u64 n_evt_total = (u64)cfg->max_evt + cfg->max_edt, n_db_total = (u64)cfg->max_db + cfg->max_edt;
-    u64 q_cap = 2 * (n_evt_total + cfg->max_edt) + 4096;
+    // one record per queued satisfy: events that fire, API satisfies (every DB- or NULL-source edge is one: bounded by the
+    // pre-slots), script ops; API batches larger than a quarter of it are applied in chunks with a drain between them
+    u64 q_cap = 2 * (n_evt_total + cfg->max_edt) + d.max_slots + 4096;
     if (cfg->flags & OCRGPU_F_LOCKABLE_DB) q_cap += 2 * (u64)cfg->max_edt + d.max_slots + 6 * (u64)cfg->max_edt; // one record per EDT + one per hand-over
     if (q_cap > 0xFFFFFFF0ull) q_cap = 0xFFFFFFF0ull;
     d.q_cap = (u32)q_cap; e->q_cap = (u32)q_cap;
@@ -1629,7 +1757,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
         d.lazy_mask = lc - 1; e->lazy_cap = lc;
         TRY(dalloc(e, (void **)&d.lazy_tab, 16 * (size_t)lc));
     }
-    TRY(dalloc(e, (void **)&d.waiters, 8 * (size_t)d.max_edges));
+    TRY(dalloc(e, (void **)&d.waiters, 16 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.log_src, 4 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.log_rec, 8 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.db, 16 * (size_t)n_db_total));
@@ -1640,6 +1768,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     u64 fired_cap = (u64)cfg->max_edt + d.max_edges + 4096; if (fired_cap > 0xFFFFFFF0ull) fired_cap = 0xFFFFFFF0ull;
     e->fired_cap = fired_cap; d.fired_cap = (u32)fired_cap;
     TRY(dalloc(e, (void **)&d.fired, 4 * (size_t)fired_cap, false));
+    TRY(dalloc(e, (void **)&d.fired_aux, 8 * (size_t)fired_cap, false));
     TRY(dalloc(e, (void **)&d.level_start, 4 * ((size_t)d.max_levels + 2)));
     TRY(dalloc(e, (void **)&d.q, sizeof(Rec) * (size_t)q_cap, false));
     TRY(dalloc(e, (void **)&d.blk_stats, 8 * 4 * MAX_GRID));
@@ -1730,8 +1859,9 @@ static int seal(ocrgpu_engine *e) {
     if (r) return r;
     k_csr_set_rows<<<nblk(used), 256, 0, e->stream>>>(d, used, e->tmp_b, e->tmp_c);
     k_csr_fill<<<g, 256, 0, e->stream>>>(d, e->tmp_c);
+    k_ready_aux_clear<<<64, 256, 0, e->stream>>>(d);
     HIPCHK(hipGetLastError());
-    e->csr_dirty = false;
+    e->csr_dirty = false; ++e->seal_epoch;
     return 0;
 }
 
@@ -1758,6 +1888,7 @@ static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool ti
         launched += batch;
         HIPCHK(hipMemcpyAsync(e->pinned_done, &d.ctrl->state[(K - 1) & 1], sizeof(State), hipMemcpyDeviceToHost, e->stream));
         if (d.send_cnt) HIPCHK(hipMemcpyAsync(e->pinned_done + 32, d.send_cnt, 128 * (size_t)d.n_loc, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(e->pinned_done + PIN_ERR, d.ctrl->err, 32, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         if (((State *)e->pinned_done)->done) break;
         if (launched >= max_launches) break;
@@ -1778,14 +1909,26 @@ static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool ti
     HIPCHK(hipGetLastError());
     return 0;
 }
+// The device counts user-level errors (Ctrl.err[], ocrgpu_stats_t.err[]) and goes on; the call during which a counter moved
+// still does all its work and then returns OCRGPU_EFAULT (once per movement), so that no caller takes a dropped record or a
+// malformed op for success.  pinned_done[PIN_ERR..+8) = Ctrl.err as of the last poll.
+static int check_fault(ocrgpu_engine *e) {
+    u64 sum = 0; for (int i = 0; i < 8; ++i) sum += e->pinned_done[PIN_ERR + i];
+    if (sum == e->err_seen) return 0;
+    e->err_seen = sum;
+    const u32 *x = e->pinned_done + PIN_ERR;
+    FAIL(OCRGPU_EFAULT, "the device flagged user-level errors: err = [%u %u %u %u %u %u %u] (double slot, late waiter, sticky re-satisfied, dead event, "
+                        "malformed op, queue/table overflow, level overflow); the call completed", x[0], x[1], x[2], x[3], x[4], x[5], x[6]);
+}
 static int drain_events(ocrgpu_engine *e) {
     if (e->defer_drain) return 0; // distributed stepping: the driver calls ocrgpu_step
-    // q_begin and q_tail sit in different cache lines of Ctrl: two 4-byte reads, one sync
+    // q_begin, q_tail and err[] sit in different cache lines of Ctrl: three small reads, one sync
     HIPCHK(hipMemcpyAsync(e->pinned_done + 33008, &e->d.ctrl->q_begin, 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(e->pinned_done + 33009, &e->d.ctrl->q_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + PIN_ERR, e->d.ctrl->err, 32, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    if (e->pinned_done[33009] <= e->pinned_done[33008]) return 0; // nothing queued: registrations only
-    return run_steps(e, 0u, ~0ull, false);
+    if (e->pinned_done[33009] > e->pinned_done[33008]) { int r = run_steps(e, 0u, ~0ull, false); if (r) return r; }
+    return check_fault(e);
 }
 
 // ---- GUID provider -----------------------------------------------------------------------------------------
@@ -1811,6 +1954,18 @@ extern "C" int ocrgpu_guid_put(ocrgpu_engine_t *e, u64 n, const u64 *guids, cons
     if ((r = stage_in(e, guids, n, where, &dg)) || (r = stage_in(e, vals, n, where, &dv))) return r;
     k_guid_put<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dg, dv);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int ocrgpu_guid_tryput(ocrgpu_engine_t *e, u64 n, const u64 *guids, const u64 *vals, u64 *held_out, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!guids || !vals || !held_out) FAIL(OCRGPU_EINVAL, "null array");
+    int r = stage_reserve(e, 3 * rup(8 * n)); if (r) return r;
+    const u64 *dg, *dv; u64 *dh;
+    if ((r = stage_in(e, guids, n, where, &dg)) || (r = stage_in(e, vals, n, where, &dv)) || (r = stage_out_alloc(e, held_out, n, where, &dh))) return r;
+    k_guid_tryput<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dg, dv, dh);
+    if ((r = stage_out_copy(e, held_out, dh, n, where))) return r;
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
 extern "C" int ocrgpu_guid_get(ocrgpu_engine_t *e, u64 n, const u64 *guids, u64 *vals_out, int where) {
@@ -1924,39 +2079,60 @@ extern "C" int ocrgpu_edt_set_scripts(ocrgpu_engine_t *e, u64 n, const u64 *edt,
     k_script_merge_latch<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dbg, dl, (u32)e->n_script);
     k_set_scripts<<<nblk(n), 256, 0, e->stream>>>(e->d, n, de, dbg, dl, (u32)e->n_script);
     e->n_script += n_ops;
+    e->csr_dirty = true; // a scripted EDT fires through its line, not through fire info sealed into waiter records
     HIPCHK(hipGetLastError());
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
 
 // ---- dependence API -----------------------------------------------------------------------------------------
+// API batches are applied in chunks of at most a quarter of the record queue, with a drain between them: every element can
+// queue one satisfy record (a DB or NULL_GUID source, a satisfied persistent source, every ocrEventSatisfySlot), and the queue
+// only rewinds when it has been drained.  (With an exchange configured the caller drains: ocrgpu_step.)
+static inline u64 api_chunk(const ocrgpu_engine *e) { u64 c = e->q_cap / 4; return c < 1024 ? 1024 : c; }
 extern "C" int ocrgpu_add_dependence(ocrgpu_engine_t *e, u64 n, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode, int where) {
     ENTER(e);
     if (n == 0) return 0;
     if (!src || !dst || !slot || !mode) FAIL(OCRGPU_EINVAL, "null array");
     if (e->edges_upper + n > e->d.max_edges) FAIL(OCRGPU_ENOMEM, "max_edges=%llu exhausted", (unsigned long long)e->d.max_edges);
-    int r = stage_reserve(e, 2 * rup(8 * n) + 2 * rup(4 * n)); if (r) return r;
-    const u64 *ds, *dd; const u32 *dsl, *dm;
-    if ((r = stage_in(e, src, n, where, &ds)) || (r = stage_in(e, dst, n, where, &dd)) || (r = stage_in(e, slot, n, where, &dsl)) ||
-        (r = stage_in(e, mode, n, where, &dm))) return r;
-    // registrations first, then the immediate satisfies this batch produced (see DESIGN.md "batch order")
-    k_add_dep<<<nblk(n), 256, 0, e->stream>>>(e->d, n, ds, dd, dsl, dm, (e->cfg.flags & OCRGPU_F_NANNY) ? 1u : 0u);
-    HIPCHK(hipGetLastError());
-    e->edges_upper += n; e->csr_dirty = true;
-    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream)); // staging buffers are reused by the next call
-    return drain_events(e);
+    const u64 chunk = api_chunk(e);
+    int fault = 0;
+    for (u64 o = 0; o < n; o += chunk) {
+        const u64 m = n - o < chunk ? n - o : chunk;
+        stage_reset(e);
+        int r = stage_reserve(e, 2 * rup(8 * m) + 2 * rup(4 * m)); if (r) return r;
+        const u64 *ds, *dd; const u32 *dsl, *dm;
+        if ((r = stage_in(e, src + o, m, where, &ds)) || (r = stage_in(e, dst + o, m, where, &dd)) || (r = stage_in(e, slot + o, m, where, &dsl)) ||
+            (r = stage_in(e, mode + o, m, where, &dm))) return r;
+        // registrations first, then the immediate satisfies this batch produced (see DESIGN.md "batch order")
+        k_add_dep<<<nblk(m), 256, 0, e->stream>>>(e->d, m, ds, dd, dsl, dm, (e->cfg.flags & OCRGPU_F_NANNY) ? 1u : 0u);
+        HIPCHK(hipGetLastError());
+        e->edges_upper += m; e->csr_dirty = true;
+        if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream)); // staging buffers are reused by the next chunk / call
+        r = drain_events(e);
+        if (r == OCRGPU_EFAULT) fault = r; else if (r) return r;
+    }
+    return fault;
 }
 extern "C" int ocrgpu_event_satisfy_slot(ocrgpu_engine_t *e, u64 n, const u64 *evt, const u64 *db, const u32 *slot, int where) {
     ENTER(e);
     if (n == 0) return 0;
     if (!evt || !db || !slot) FAIL(OCRGPU_EINVAL, "null array");
-    int r = stage_reserve(e, 2 * rup(8 * n) + rup(4 * n)); if (r) return r;
-    const u64 *de, *dd; const u32 *dsl;
-    if ((r = stage_in(e, evt, n, where, &de)) || (r = stage_in(e, db, n, where, &dd)) || (r = stage_in(e, slot, n, where, &dsl))) return r;
-    k_satisfy<<<nblk(n), 256, 0, e->stream>>>(e->d, n, de, dd, dsl);
-    HIPCHK(hipGetLastError());
-    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
-    return drain_events(e);
+    const u64 chunk = api_chunk(e);
+    int fault = 0;
+    for (u64 o = 0; o < n; o += chunk) {
+        const u64 m = n - o < chunk ? n - o : chunk;
+        stage_reset(e);
+        int r = stage_reserve(e, 2 * rup(8 * m) + rup(4 * m)); if (r) return r;
+        const u64 *de, *dd; const u32 *dsl;
+        if ((r = stage_in(e, evt + o, m, where, &de)) || (r = stage_in(e, db + o, m, where, &dd)) || (r = stage_in(e, slot + o, m, where, &dsl))) return r;
+        k_satisfy<<<nblk(m), 256, 0, e->stream>>>(e->d, m, de, dd, dsl);
+        HIPCHK(hipGetLastError());
+        if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+        r = drain_events(e);
+        if (r == OCRGPU_EFAULT) fault = r; else if (r) return r;
+    }
+    return fault;
 }
 extern "C" int ocrgpu_event_destroy(ocrgpu_engine_t *e, u64 n, const u64 *evt, int where) {
     ENTER(e);
@@ -2014,7 +2190,7 @@ extern "C" int ocrgpu_resolve(ocrgpu_engine_t *e, u64 max_levels, ocrgpu_stats_t
     int r = run_steps(e, 0xFFFFFFFFu, max_launches, true);
     if (r) return r;
     if (stats_out) { r = fetch_stats(e, stats_out); if (r) return r; e->last = *stats_out; }
-    return 0;
+    return check_fault(e); // stats_out is filled either way
 }
 extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *has_ready_out, u64 *pending_records_out,
                            u32 *send_counts_out) {
@@ -2035,26 +2211,19 @@ extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *
         if (!e->d.send_cnt) FAIL(OCRGPU_EINVAL, "exchange not configured");
         for (u32 l = 0; l < e->d.n_loc; ++l) { u32 c = e->pinned_done[32 + 32 * l]; send_counts_out[l] = c > e->d.send_cap ? e->d.send_cap : c; }
     }
-    return 0;
+    return check_fault(e); // the outputs above are filled either way
 }
 
-extern "C" int ocrgpu_pop_ready(ocrgpu_engine_t *e, u64 max_edts, u64 max_deps, u64 *n_edts_out, u64 *n_deps_out, u64 *param0_out,
-                                u32 *depc_out, u32 *dep_first_out, u64 *dep_guid_out, u64 *dep_value_out) {
-    ENTER(e);
-    if (!n_edts_out || !n_deps_out) FAIL(OCRGPU_EINVAL, "null argument");
-    if ((max_edts && (!param0_out || !depc_out || !dep_first_out)) || (max_deps && (!dep_guid_out || !dep_value_out))) FAIL(OCRGPU_EINVAL, "null array");
-    if (max_edts > 0xFFFFFFFFull || max_deps > 0xFFFFFFFFull) FAIL(OCRGPU_EINVAL, "capacity above 2^32");
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 33010, &e->d.ctrl->r_end, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    const u32 r_end = e->pinned_done[33010];
-    *n_edts_out = 0; *n_deps_out = 0;
-    if (r_end <= e->pop_cursor) return 0;
-    int r = stage_reserve(e, 256 + rup(8 * max_edts) + 2 * rup(4 * max_edts) + 2 * rup(8 * max_deps)); if (r) return r;
-    auto carve = [&](size_t bytes) { char *p = e->stage_dev + e->stage_dev_off; e->stage_dev_off += rup(bytes); return p; };
+// Shared by ocrgpu_pop_ready (buf = the staging arena, grown on demand) and ocrgpu_pop_ready_noalloc (buf = this device's
+// copy of the static `scratch` array): counters in the first 256 bytes, then the five output arrays.
+static int pop_ready_into(ocrgpu_engine *e, char *buf, u32 r_end, u64 max_edts, u64 max_deps, u64 *n_edts_out, u64 *n_deps_out, u64 *param0_out,
+                          u32 *depc_out, u32 *dep_first_out, u64 *dep_guid_out, u64 *dep_value_out) {
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { char *p = buf + off; off += rup(bytes); return p; };
     u32 *cnt = (u32 *)carve(256);
     u64 *dp0 = (u64 *)carve(8 * max_edts); u32 *ddc = (u32 *)carve(4 * max_edts), *ddf = (u32 *)carve(4 * max_edts);
     u64 *dgd = (u64 *)carve(8 * max_deps), *dvl = (u64 *)carve(8 * max_deps);
-    HIPCHK(hipMemsetAsync(cnt, 0, 8, e->stream));
+    HIPCHK(hipMemsetAsync(cnt, 0, 256, e->stream)); // the buffer keeps the last call's contents: the two counters start at zero
     u64 span = r_end - e->pop_cursor; u32 g = nblk(span); if (g > 4096) g = 4096;
     k_pop_ready<<<g, 256, 0, e->stream>>>(e->d, e->pop_cursor, r_end, (u32)max_edts, (u32)max_deps, cnt, dp0, ddc, ddf, dgd, dvl);
     HIPCHK(hipMemcpyAsync(e->pinned_done + 33012, cnt, 8, hipMemcpyDeviceToHost, e->stream));
@@ -2075,6 +2244,63 @@ extern "C" int ocrgpu_pop_ready(ocrgpu_engine_t *e, u64 max_edts, u64 max_deps, 
     HIPCHK(hipStreamSynchronize(e->stream));
     e->pop_cursor = r_end;
     return 0;
+}
+static int pop_ready_args(ocrgpu_engine *e, u64 max_edts, u64 max_deps, u64 *n_edts_out, u64 *n_deps_out, u64 *param0_out, u32 *depc_out,
+                          u32 *dep_first_out, u64 *dep_guid_out, u64 *dep_value_out, u32 *r_end_out) {
+    if (!n_edts_out || !n_deps_out) FAIL(OCRGPU_EINVAL, "null argument");
+    if ((max_edts && (!param0_out || !depc_out || !dep_first_out)) || (max_deps && (!dep_guid_out || !dep_value_out))) FAIL(OCRGPU_EINVAL, "null array");
+    if (max_edts > 0xFFFFFFFFull || max_deps > 0xFFFFFFFFull) FAIL(OCRGPU_EINVAL, "capacity above 2^32");
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33010, &e->d.ctrl->r_end, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *r_end_out = e->pinned_done[33010];
+    *n_edts_out = 0; *n_deps_out = 0;
+    return 0;
+}
+extern "C" int ocrgpu_pop_ready(ocrgpu_engine_t *e, u64 max_edts, u64 max_deps, u64 *n_edts_out, u64 *n_deps_out, u64 *param0_out,
+                                u32 *depc_out, u32 *dep_first_out, u64 *dep_guid_out, u64 *dep_value_out) {
+    ENTER(e);
+    u32 r_end;
+    int r = pop_ready_args(e, max_edts, max_deps, n_edts_out, n_deps_out, param0_out, depc_out, dep_first_out, dep_guid_out, dep_value_out, &r_end);
+    if (r) return r;
+    if (r_end <= e->pop_cursor) return 0;
+    r = stage_reserve(e, 256 + rup(8 * max_edts) + 2 * rup(4 * max_edts) + 2 * rup(8 * max_deps)); if (r) return r;
+    return pop_ready_into(e, e->stage_dev, r_end, max_edts, max_deps, n_edts_out, n_deps_out, param0_out, depc_out, dep_first_out, dep_guid_out, dep_value_out);
+}
+
+// ---- the entry point that allocates nothing ----------------------------------------------------------------------
+// ocrgpu_pop_ready stages its counters and its five output arrays in device memory it may have to (re)allocate.  Callers
+// that cannot allocate (a worker loop under a harness that forbids hipMalloc, code between graph captures, tight serving
+// loops) get the same call on a file-scope device array of fixed size.  Every GPU holds its own copy of the array at its own
+// address: ocrgpu_init asks for it once per device, with that device current, and host code only ever uses that pointer.
+// One array per GPU: calls that overlap on one GPU (two engines, two threads) race on it; it keeps the last call's contents.
+#define NOALLOC_MAX_EDTS 32768u
+#define NOALLOC_MAX_DEPS 131072u
+#define NOALLOC_BYTES (256u + 16u * NOALLOC_MAX_EDTS + 16u * NOALLOC_MAX_DEPS + 5u * 256u)   /* 2.5 MiB + the carve padding */
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+#define NOALLOC_MAX_DEVICES 64
+static unsigned char *g_scratch_ptr[NOALLOC_MAX_DEVICES]; // device address of `scratch` on each GPU (hipGetSymbolAddress), 0 = not asked yet
+static int scratch_setup(int device) { // called by ocrgpu_init with `device` current
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return 0; // such a device has no no-alloc entry point (it says so when called)
+    if (g_scratch_ptr[device]) return 0;
+    void *ptr = nullptr;
+    HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) FAIL(OCRGPU_EHIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+    g_scratch_ptr[device] = (unsigned char *)ptr;
+    return 0;
+}
+extern "C" int ocrgpu_pop_ready_noalloc(ocrgpu_engine_t *e, u64 max_edts, u64 max_deps, u64 *n_edts_out, u64 *n_deps_out, u64 *param0_out,
+                                        u32 *depc_out, u32 *dep_first_out, u64 *dep_guid_out, u64 *dep_value_out) {
+    ENTER(e);
+    if (max_edts > NOALLOC_MAX_EDTS || max_deps > NOALLOC_MAX_DEPS)
+        FAIL(OCRGPU_EINVAL, "ocrgpu_pop_ready_noalloc: room for %llu EDTs / %llu deps asked, the static scratch holds at most %u / %u (use ocrgpu_pop_ready)",
+             (unsigned long long)max_edts, (unsigned long long)max_deps, NOALLOC_MAX_EDTS, NOALLOC_MAX_DEPS);
+    unsigned char *ptr = (e->device >= 0 && e->device < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[e->device] : nullptr;
+    if (!ptr) FAIL(OCRGPU_ENOTSUP, "ocrgpu_pop_ready_noalloc: no scratch address for device %d", e->device);
+    u32 r_end;
+    int r = pop_ready_args(e, max_edts, max_deps, n_edts_out, n_deps_out, param0_out, depc_out, dep_first_out, dep_guid_out, dep_value_out, &r_end);
+    if (r) return r;
+    if (r_end <= e->pop_cursor) return 0;
+    return pop_ready_into(e, (char *)ptr, r_end, max_edts, max_deps, n_edts_out, n_deps_out, param0_out, depc_out, dep_first_out, dep_guid_out, dep_value_out);
 }
 
 extern "C" int ocrgpu_step_info(ocrgpu_engine_t *e, u64 *out4) {
@@ -2127,14 +2353,12 @@ extern "C" int ocrgpu_exchange_apply_strided(ocrgpu_engine_t *e, const void *rec
         cp[s] = counts[s]; cp[n_src + s] = (u32)total; total += counts[s]; if (counts[s] > mx) mx = counts[s];
     }
     if (total == 0) return 0;
-    if ((u64)e->n_db + total > e->cfg.max_db) FAIL(OCRGPU_ENOMEM, "max_db=%u exhausted by proxy datablocks", e->cfg.max_db);
     int r = stage_reserve(e, rup(8 * (size_t)n_src)); if (r) return r;
     // the counts go through pinned memory that outlives this call (two alternating halves, each guarded by an event), so the
     // copy can stay asynchronous
     if (n_src > 200) { // beyond the pinned scratch: stage from the vector and wait
         const u32 *dc; if ((r = stage_in(e, cp.data(), 2 * (u64)n_src, OCRGPU_HOST, &dc))) return r;
         k_exchange_apply_strided<<<nblk((u64)n_src * mx), 256, 0, e->stream>>>(e->d, n_src, stride_records, mx, dc, (const SendRec *)recs_dev, e->n_db);
-        e->n_db += (u32)total;
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(e->stream));
         return 0;
@@ -2147,7 +2371,6 @@ extern "C" int ocrgpu_exchange_apply_strided(ocrgpu_engine_t *e, const void *rec
     const u32 *dc; if ((r = stage_in(e, pin, 2 * (u64)n_src, OCRGPU_HOST, &dc))) return r;
     HIPCHK(hipEventRecord(e->apply_ev[half], e->stream));
     k_exchange_apply_strided<<<nblk((u64)n_src * mx), 256, 0, e->stream>>>(e->d, n_src, stride_records, mx, dc, (const SendRec *)recs_dev, e->n_db);
-    e->n_db += (u32)total;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2155,11 +2378,9 @@ extern "C" int ocrgpu_exchange_apply(ocrgpu_engine_t *e, const void *recs, u64 n
     ENTER(e);
     if (n == 0) return 0;
     if (!recs) FAIL(OCRGPU_EINVAL, "null records");
-    if ((u64)e->n_db + n > e->cfg.max_db) FAIL(OCRGPU_ENOMEM, "max_db=%u exhausted by proxy datablocks", e->cfg.max_db);
     int r = stage_reserve(e, rup(32 * n)); if (r) return r;
     const SendRec *dr; if ((r = stage_in(e, (const SendRec *)recs, n, where, &dr))) return r;
     k_exchange_apply<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dr, e->n_db);
-    e->n_db += (u32)n;
     HIPCHK(hipGetLastError());
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
@@ -2190,19 +2411,22 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     s.chan_wait_used = e->pinned_done[33014]; s.chan_sat_used = e->pinned_done[33015]; // CHANNEL rings in use
     if (s.chan_wait_used > d.max_edges) s.chan_wait_used = (u32)d.max_edges;
     if (s.chan_sat_used > d.chan_sat_cap) s.chan_sat_used = d.chan_sat_cap;
-    HIPCHK(hipMalloc((void **)&s.chan_wait, 8 * (size_t)s.chan_wait_used + 64));
+    HIPCHK(hipMalloc((void **)&s.chan_wait, 16 * (size_t)s.chan_wait_used + 64));
     HIPCHK(hipMalloc((void **)&s.chan_sat, 4 * (size_t)s.chan_sat_used + 64));
-    if (s.chan_wait_used) HIPCHK(hipMemcpyAsync(s.chan_wait, d.waiters + (d.max_edges - s.chan_wait_used), 8 * (size_t)s.chan_wait_used, hipMemcpyDeviceToDevice, e->stream));
+    if (s.chan_wait_used) HIPCHK(hipMemcpyAsync(s.chan_wait, d.waiters + (d.max_edges - s.chan_wait_used), 16 * (size_t)s.chan_wait_used, hipMemcpyDeviceToDevice, e->stream));
     if (s.chan_sat_used) HIPCHK(hipMemcpyAsync(s.chan_sat, d.chan_sat, 4 * (size_t)s.chan_sat_used, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMalloc((void **)&s.fired, 4 * (size_t)s.n_fired_entries + 16));
+    HIPCHK(hipMalloc((void **)&s.fired_aux, 8 * (size_t)s.n_fired_entries + 16));
     HIPCHK(hipMalloc((void **)&s.ctrl, sizeof(Ctrl)));
     s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt; s.n_db = e->n_db; e->snap_pop_cursor = e->pop_cursor;
+    s.edges_upper = e->edges_upper; s.seal_epoch = e->seal_epoch; s.err_seen = e->err_seen;
     HIPCHK(hipMemcpyAsync(s.edt, d.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(s.evt, d.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     if (e->n_evt) HIPCHK(hipMemcpyAsync(s.counted, d.counted, 8 * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(s.lazy_tab, d.lazy_tab, 16 * (size_t)e->lazy_cap, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_slots) HIPCHK(hipMemcpyAsync(s.slots, d.slots, 4 * (size_t)s.n_slots, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(s.fired, d.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
+    if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(s.fired_aux, d.fired_aux, 8 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(s.ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
     return 0;
 }
@@ -2212,18 +2436,24 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     if (!s.valid) FAIL(OCRGPU_EINVAL, "no snapshot taken");
     if (s.n_edt != e->n_edt || s.n_evt != e->n_evt) FAIL(OCRGPU_EINVAL, "objects were created after the snapshot");
     e->pop_cursor = e->snap_pop_cursor;
-    e->n_db = s.n_db; // proxy datablocks cloned from other partitions since the snapshot are dropped
+    e->n_db = s.n_db; // (proxy datablocks cloned from other partitions since the snapshot go with Ctrl.proxy_used)
+    // the registration log is append-only and Ctrl.log_tail goes back with Ctrl: what was registered since the snapshot is
+    // forgotten, on the host side too; if the rows were rebuilt meanwhile (waiters[] has another layout than the restored
+    // row_begin / deg describe), the next run seals again from the restored log and states
+    e->edges_upper = s.edges_upper; e->err_seen = s.err_seen; // Ctrl.err[] goes back with Ctrl
+    if (e->seal_epoch != s.seal_epoch || e->csr_dirty) e->csr_dirty = true;
     if (e->d.send_cnt) k_exchange_reset<<<1, 1024, 0, e->stream>>>(e->d);
     if (e->dbl && s.dbl) HIPCHK(hipMemcpyAsync(e->dbl, s.dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.edt, s.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.evt, s.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     if (e->n_evt) HIPCHK(hipMemcpyAsync(d.counted, s.counted, 8 * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.lazy_tab, s.lazy_tab, 16 * (size_t)e->lazy_cap, hipMemcpyDeviceToDevice, e->stream));
-    if (s.chan_wait_used) HIPCHK(hipMemcpyAsync(d.waiters + (d.max_edges - s.chan_wait_used), s.chan_wait, 8 * (size_t)s.chan_wait_used, hipMemcpyDeviceToDevice, e->stream));
+    if (s.chan_wait_used) HIPCHK(hipMemcpyAsync(d.waiters + (d.max_edges - s.chan_wait_used), s.chan_wait, 16 * (size_t)s.chan_wait_used, hipMemcpyDeviceToDevice, e->stream));
     if (s.chan_sat_used) HIPCHK(hipMemcpyAsync(d.chan_sat, s.chan_sat, 4 * (size_t)s.chan_sat_used, hipMemcpyDeviceToDevice, e->stream));
     // pre-slot words carry the "satisfied" marks: overflow words go back to what they were (inline ones are in the lines)
     if (s.n_slots) HIPCHK(hipMemcpyAsync(d.slots, s.slots, 4 * (size_t)s.n_slots, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(d.fired, s.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
+    if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(d.fired_aux, s.fired_aux, 8 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.ctrl, s.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemsetAsync(d.blk_stats, 0, 8 * 4 * MAX_GRID, e->stream)); // statistics restart with the re-armed DAG
     return 0;

@@ -44,7 +44,9 @@ static void die(const char *fmt, ...) {
 }
 static void *xrealloc(void *p, size_t n) { void *q = realloc(p, n ? n : 1); if (!q) die("out of host memory"); return q; }
 #define GROW(arr, n, cap) do { if ((n) >= (cap)) { (cap) = (cap) ? 2 * (cap) : 1024; (arr) = xrealloc((arr), (cap) * sizeof *(arr)); } } while (0)
-#define CHK(call) do { int _rc = (call); if (_rc) die("%s failed (%d): %s", #call, _rc, ocrgpu_last_error()); } while (0)
+/* OCRGPU_EFAULT = the engine counted a user-level error (what the reference ASSERTs on) and completed the call: the program
+ * runs on and ends with exit code 73 and the error counters on stderr (shim_fini) */
+#define CHK(call) do { int _rc = (call); if (_rc && _rc != OCRGPU_EFAULT) die("%s failed (%d): %s", #call, _rc, ocrgpu_last_error()); } while (0)
 
 static ocrgpu_engine_t *G;
 static int g_shutdown, g_exit_code, g_verbose;

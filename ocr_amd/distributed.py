@@ -248,7 +248,10 @@ class Partition:
         if self.my_evts:
             evs[np.asarray(self.my_evts)] = eng.read_events(0, 0, len(self.my_evts))
         if self.my_dbs:
-            dbv[np.asarray(self.my_dbs)] = eng.read_dbs(0, 0, len(self.my_dbs))
+            mine = np.asarray(self.my_dbs)
+            idx = eng.guid_get(self.db_guid[mine]).astype(np.int64) - 1     # engine index of each explicit DB this rank made
+            assert (idx >= 0).all()
+            dbv[mine] = eng.read_dbs(0, 0, int(idx.max()) + 1)[idx]
 
 
 # ---- the per-level protocol ------------------------------------------------------------------------------------

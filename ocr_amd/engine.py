@@ -22,6 +22,7 @@ HOST, DEVICE = 0, 1
 GUIDS_GIVEN = 4   # OR into `where` of the create calls: guid arrays are inputs (ocrgpu.h)
 F_NANNY, F_TIMING = 1, 2
 F_LOCKABLE_DB = 8  # datablocks arbitrate their acquire modes (the cfg's datablockfactory=Lockable)
+EFAULT = -14       # OCRGPU_EFAULT: the device flagged a user-level error during the call (which completed)
 
 
 def LATCH_DELTA(k):
@@ -60,7 +61,7 @@ SCRIPT_OP_DT = np.dtype([("target", "<u8"), ("payload", "<u8"), ("slot", "<u4"),
 assert SCRIPT_OP_DT.itemsize == 24
 
 EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error", "ocrgpu_abi_version",
-           "ocrgpu_guid_reserve", "ocrgpu_guid_put", "ocrgpu_guid_get", "ocrgpu_guid_remove",
+           "ocrgpu_guid_reserve", "ocrgpu_guid_put", "ocrgpu_guid_tryput", "ocrgpu_guid_get", "ocrgpu_guid_remove",
            "ocrgpu_event_create", "ocrgpu_db_create", "ocrgpu_edt_create", "ocrgpu_edt_set_scripts",
            "ocrgpu_set_hash_tag_base", "ocrgpu_add_dependence", "ocrgpu_event_satisfy_slot", "ocrgpu_event_destroy", "ocrgpu_edt_release_dbs",
            "ocrgpu_resolve", "ocrgpu_step", "ocrgpu_step_info", "ocrgpu_pop_ready", "ocrgpu_exchange_apply_strided", "ocrgpu_exchange_config", "ocrgpu_exchange_counts",
@@ -98,8 +99,11 @@ class Engine:
     """One GPU partition of the dependence engine (one policy-domain location)."""
 
     def __init__(self, max_edt, max_evt=16, max_db=16, max_slots=None, max_edges=None, device=0, location=0,
-                 flags=0, max_levels=0, guid_slots=0):
+                 flags=0, max_levels=0, guid_slots=0, tolerate_faults=False):
+        """tolerate_faults: a call that returns OCRGPU_EFAULT (the device counted a user-level error, did the rest of its
+        work and says so) is recorded in ``self.faults`` instead of raising -- for tests of ill-formed programs."""
         self.lib = load_library()
+        self.tolerate_faults, self.faults = tolerate_faults, 0
         cfg = Config(max_edt=max_edt, max_evt=max_evt, max_db=max_db, location=location,
                      max_slots=max_slots if max_slots is not None else 8 * max_edt,
                      max_edges=max_edges if max_edges is not None else 8 * max_edt, guid_slots=guid_slots,
@@ -109,6 +113,9 @@ class Engine:
         self._chk(self.lib.ocrgpu_init(C.byref(self.h), device, C.byref(cfg)))
 
     def _chk(self, rc):
+        if rc == EFAULT and self.tolerate_faults:
+            self.faults += 1
+            return
         if rc != 0:
             raise OcrGpuError(rc, (self.lib.ocrgpu_last_error() or b"").decode())
 
@@ -132,6 +139,13 @@ class Engine:
     def guid_put(self, guids, vals):
         guids, vals = np.ascontiguousarray(guids, np.uint64), np.ascontiguousarray(vals, np.uint64)
         self._chk(self.lib.ocrgpu_guid_put(self.h, C.c_uint64(len(guids)), _ptr(guids), _ptr(vals), HOST))
+
+    def guid_tryput(self, guids, vals):
+        """insert unless present; returns the value the table holds for each guid afterwards (hashtable TryPut)"""
+        guids, vals = np.ascontiguousarray(guids, np.uint64), np.ascontiguousarray(vals, np.uint64)
+        out = np.empty(len(guids), dtype=np.uint64)
+        self._chk(self.lib.ocrgpu_guid_tryput(self.h, C.c_uint64(len(guids)), _ptr(guids), _ptr(vals), _ptr(out), HOST))
+        return out
 
     def guid_get(self, guids):
         guids = np.ascontiguousarray(guids, np.uint64)
@@ -317,12 +331,13 @@ class StreamProgram:
     """An op stream loaded into an :class:`Engine`: the same role oracle/ocr_replay.c plays for the
     reference runtime, but every op becomes (part of) one batched C-ABI call."""
 
-    def __init__(self, s: OpStream, device=0, flags=0, engine=None, slack=0):
+    def __init__(self, s: OpStream, device=0, flags=0, engine=None, slack=0, tolerate_faults=False):
         self.s = s
         n_slots = int(s.edt["depc"].sum())
         n_adddep = int((s.main["op"] == ops.OP_ADD_DEP).sum())
         self.eng = engine or Engine(max_edt=max(s.n_edt, 1) + slack, max_evt=max(s.n_evt, 1), max_db=max(s.n_db, 1),
-                                    max_slots=n_slots + 1, max_edges=n_adddep + 1 + ops.channel_ring_slots(s), device=device, flags=flags)
+                                    max_slots=n_slots + 1, max_edges=n_adddep + 1 + ops.channel_ring_slots(s), device=device, flags=flags,
+                                    tolerate_faults=tolerate_faults)
         self.edt_guid = np.zeros(s.n_edt, np.uint64)
         self.evt_guid = np.zeros(s.n_evt_total, np.uint64)
         self.db_guid = np.zeros(s.n_db_total, np.uint64)
@@ -436,9 +451,9 @@ class StreamProgram:
         return Result(level, v, evs, dbv)
 
 
-def run_stream(s: OpStream, device=0, flags=F_NANNY):
+def run_stream(s: OpStream, device=0, flags=F_NANNY, tolerate_faults=False):
     """Build + resolve + read back. Returns (Result, Stats)."""
-    p = StreamProgram(s, device=device, flags=flags).build()
+    p = StreamProgram(s, device=device, flags=flags, tolerate_faults=tolerate_faults).build()
     st = p.resolve()
     r = p.result()
     p.eng.close()

@@ -149,6 +149,34 @@ def counted_events():
     return b.finish([w1, w2, e1, l1, l2, h, g] + c, start)
 
 
+def counted_after_null_preslot():
+    """A COUNTED dependence added AFTER an earlier DB_MODE_NULL pre-slot of the EDT was satisfied by an event: the EDT's
+    frontier is already past that pre-slot, so the registration is made (and counted) at once and the satisfy that follows
+    serves it and destroys the event (registerSignalerTaskHc hc-task.c:1391-1405; hc-event.c:1211-1238).  Second EDT: the
+    same with the pre-slot still unsatisfied -- the registration waits for the frontier and is made when it arrives."""
+    b = Builder("counted_after_null_preslot")
+    start = b.evt(EVT_ONCE)
+    x = b.evt(EVT_ONCE)
+    e0 = b.edt(2)
+    b.add_dep(x, e0, 0, MODE_NULL)
+    b.satisfy(x, 0)                        # pre-slot 0 is satisfied before the COUNTED source exists
+    c0 = b.evt(EVT_COUNTED, 1)
+    b.add_dep(c0, e0, 1, MODE_RO)
+    d = b.db(0x7777)
+    b.satisfy(c0, d)                       # serves its one registration: destroyed, e0 is ready
+    y = b.evt(EVT_ONCE)
+    e1 = b.edt(3)
+    b.add_dep(y, e1, 0, MODE_NULL)
+    b.add_dep(start, e1, 1, MODE_NULL)
+    c1 = b.evt(EVT_COUNTED, 1)
+    b.add_dep(c1, e1, 2, MODE_RO)          # held back: pre-slot 0 is not satisfied yet
+    b.satisfy(c1, d)                       # nothing registered yet: stays satisfied ...
+    g = b.edt(1, BODY_NOP)
+    b.add_dep(start, g, 0, MODE_RO)
+    b.script_satisfy(g, y, 0)              # ... until level 0 satisfies pre-slot 0: frontier reaches 2, counted, destroyed
+    return b.finish([e0, e1, g], start)
+
+
 def idem_double_satisfy():
     """Rule 3: the 2nd satisfy of an IDEM is ignored; everybody sees the first payload."""
     b = Builder("idem_double_satisfy")
@@ -308,7 +336,7 @@ def channel_events():
     return b.finish([a, bb, c, drv], start)
 
 
-SEMANTIC = [channel_events, latch_decr_then_incr, latch_incr2_decr2, latch_init_counter, once_no_waiters, sticky_early_and_late,
+SEMANTIC = [counted_after_null_preslot, channel_events, latch_decr_then_incr, latch_incr2_decr2, latch_init_counter, once_no_waiters, sticky_early_and_late,
             counted_events, idem_double_satisfy, mode_null_forces_null, db_and_null_sources, event_chain, forward_and_nop,
             destroy_and_unfired, wide_fanin]
 

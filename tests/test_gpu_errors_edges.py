@@ -61,9 +61,13 @@ def test_ill_formed_programs_count_the_same_errors(name):
     ref, stats = O.run_restatement(s, return_stats=True)
     want = [int(x) for x in stats[8:]]
     assert sum(want) > 0, "the program is meant to be ill-formed"
-    r, st = engine.run_stream(s, flags=engine.F_NANNY)
+    r, st = engine.run_stream(s, flags=engine.F_NANNY, tolerate_faults=True)
     assert list(st.err) == want
     assert r.level[0] == ref.level[0] == 0          # the well-formed part still runs
+    # ... and the call during which the device counted the error says so: OCRGPU_EFAULT, after doing its work
+    with pytest.raises(engine.OcrGpuError) as ei:
+        engine.run_stream(s, flags=engine.F_NANNY)
+    assert ei.value.code == engine.EFAULT and "flagged" in str(ei.value)
 
 
 def test_empty_batches_and_empty_program():
@@ -173,3 +177,63 @@ def test_interrupted_resolve_leaves_no_body_owed():
     assert calls > 2 and int(st.fired) == s.n_edt
     assert want.diff(p.result()) == []
     p.eng.close()
+
+
+def test_api_batch_larger_than_the_record_queue():
+    """Every element of one ocrgpu_event_satisfy_slot / ocrgpu_add_dependence call can queue a satisfy record; a batch far
+    larger than the queue (sized from the engine's capacities) is applied in chunks with a drain between them: nothing
+    is dropped, nothing is flagged (round-1 advice: the drop was silent and the call returned 0)."""
+    eng = engine.Engine(max_edt=8, max_evt=8, max_db=8, max_edges=200_000)   # record queue: a few thousand entries
+    n = 150_000
+    lt = eng.event_create([EVT_LATCH], [0])
+    g, _, _ = eng.edt_create([1], [BODY_NOP], [5])
+    eng.add_dependence(lt, g, [0], [MODE_NULL])
+    eng.event_satisfy_slot(np.repeat(lt, n), None, np.ones(n, np.uint32))             # n INCRs in one call
+    assert eng.resolve().fired == 0
+    eng.event_satisfy_slot(np.repeat(lt, n), None, np.zeros(n, np.uint32))            # n DECRs: the last one fires it
+    st = eng.resolve()
+    assert sum(st.err) == 0 and st.fired == 1 and st.evt_sat == 2 * n
+    # one add-dependence batch of DB-source edges onto IDEM events, each an immediate satisfy record
+    ev = eng.event_create([EVT_IDEM] * 4)
+    d = eng.db_create([9])
+    eng.add_dependence(np.repeat(d, n), np.tile(ev, n // 4 + 1)[:n], np.zeros(n, np.uint32), np.zeros(n, np.uint32))
+    assert sum(eng.stats().err) == 0
+    eng.close()
+
+
+def test_restore_after_the_rows_were_rebuilt():
+    """snapshot -> resolve -> add_dependence -> resolve (the CSR is sealed again: the rows of the events still alive move)
+    -> restore: the restored rows must not point into the rebuilt layout, and the edge budget goes back too
+    (round-1 advice on ocrgpu_restore)."""
+    b = Builder("restore_reseal")
+    start = b.evt(EVT_ONCE)
+    keep = b.evt(EVT_STICKY)                      # stays alive across the first resolve
+    es = [b.edt(1, BODY_HASH) for _ in range(40)]
+    for e in es:
+        b.add_dep(start, e, 0, MODE_RO)
+    late = [b.edt(1, BODY_HASH) for _ in range(8)]
+    for e in late[:4]:
+        b.add_dep(keep, e, 0, MODE_RO)
+    s = b.finish(es, None)
+    from ocr_amd.opstream import OP_ADD_DEP
+    n_adddep = int((s.main["op"] == OP_ADD_DEP).sum())
+    eng = engine.Engine(max_edt=s.n_edt, max_evt=s.n_evt, max_db=1, max_slots=int(s.edt["depc"].sum()) + 1,
+                        max_edges=n_adddep + 1 + 4)          # room for ONE round of the four late edges, not three
+    p = engine.StreamProgram(s, engine=eng)
+    p.build()
+    g_start, g_keep = p._guids(np.array([start, keep], np.uint64))
+    eng.snapshot()
+    def run():
+        eng.event_satisfy_slot([g_start])
+        st = eng.resolve()
+        assert sum(st.err) == 0
+        return p.result()
+    first = run()
+    for rounds in range(3):                        # more rounds than the edge capacity would allow if it leaked
+        eng.add_dependence(np.repeat(g_keep, 4), p._guids(np.array(late[4:], np.uint64)), [0] * 4, [MODE_RO] * 4)
+        eng.event_satisfy_slot([g_keep])           # seals the new rows and fans them out
+        eng.resolve()
+        eng.restore()
+        again = run()
+        assert first.diff(again) == [], rounds
+    eng.close()

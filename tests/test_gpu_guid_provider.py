@@ -79,3 +79,40 @@ def test_engine_objects_resolve_and_dead_events_do_not():
     assert list(eng.guid_get(ev)) == [0, 2, 3]
     eng.event_destroy(ev[1:2])
     assert list(eng.guid_get(ev)) == [0, 0, 3]
+
+
+def test_removed_slots_are_reused_and_tryput():
+    """hashtable.c:498-554: remove gives capacity back (a put takes over the first tombstone on its way once it knows the
+    key is not further down), and TryPut inserts only when the key is absent and reports the value the table holds."""
+    eng = E.Engine(max_edt=16, max_evt=16, max_db=16, guid_slots=1024)
+    g = eng.guid_reserve(E.KIND_DB, 6000)
+    live = {}
+    rng = np.random.default_rng(7)
+    for rnd in range(6):                                     # 6 x 900 puts through a 1024-slot table: only works if tombstones are reused
+        blk = g[rnd * 1000: rnd * 1000 + 900]
+        v = rng.integers(1, 1 << 62, size=len(blk), dtype=np.uint64)
+        eng.guid_put(blk, v)
+        live.update(zip(blk.tolist(), v.tolist()))
+        assert np.array_equal(eng.guid_get(blk), v)
+        gone = blk[:880]
+        eng.guid_remove(gone)
+        for k in gone.tolist():
+            del live[k]
+    keys = np.array(sorted(live), np.uint64)
+    assert np.array_equal(eng.guid_get(keys), np.array([live[k] for k in keys.tolist()], np.uint64))
+    assert not eng.guid_get(g[:880]).any()
+    assert sum(eng.stats().err) == 0
+    # TryPut: present -> the old value is reported and kept; absent -> inserted; duplicates inside one batch -> one winner
+    some = keys[:10]
+    held = eng.guid_tryput(some, np.full(10, 5, np.uint64))
+    assert np.array_equal(held, np.array([live[k] for k in some.tolist()], np.uint64))
+    fresh = g[5990:5995]
+    batch = np.repeat(fresh, 64)
+    vals = np.arange(1, len(batch) + 1, dtype=np.uint64)
+    held = eng.guid_tryput(batch, vals)
+    for k in range(5):
+        h = held[k * 64:(k + 1) * 64]
+        assert len(set(h.tolist())) == 1 and h[0] in vals[k * 64:(k + 1) * 64]      # everybody saw the one value that won
+    assert np.array_equal(eng.guid_get(fresh), held[::64])
+    assert sum(eng.stats().err) == 0
+    eng.close()
