@@ -220,6 +220,17 @@ int ocrgpu_pop_ready(ocrgpu_engine_t *e, uint64_t max_edts, uint64_t max_deps, u
                      uint64_t *param0_out, uint32_t *depc_out, uint32_t *dep_first_out, uint64_t *dep_guid_out,
                      uint64_t *dep_value_out);
 
+/* ocrgpu_pop_ready for callers that cannot allocate.  No counterpart in the reference: it is for worker loops that run
+ * where hipMalloc is not allowed (between HIP graph captures, tight serving loops, harnesses that forbid allocation).
+ * Same arguments, results and errors as ocrgpu_pop_ready, but the counters and the staging of the five output arrays live
+ * in a device array of FIXED size that is part of the library (2.5 MiB per GPU, held until the process ends) instead of the
+ * engine's growable staging arena: the call allocates and frees nothing.  Limits: max_edts <= 32768 and
+ * max_deps <= 131072, a larger request is refused with OCRGPU_EINVAL (pop in several calls, or use ocrgpu_pop_ready).
+ * Every engine on one GPU shares that GPU's array: calls that overlap on one GPU (two threads, two engines) race. */
+int ocrgpu_pop_ready_noalloc(ocrgpu_engine_t *e, uint64_t max_edts, uint64_t max_deps, uint64_t *n_edts_out, uint64_t *n_deps_out,
+                             uint64_t *param0_out, uint32_t *depc_out, uint32_t *dep_first_out, uint64_t *dep_guid_out,
+                             uint64_t *dep_value_out);
+
 /* ---- cross-partition satisfies (replace ocrCommPlatformFcts_t.sendMessage/pollMessage for PD_MSG_DEP_SATISFY,
  *      ocr/src/inc/ocr-comm-platform.h:55-199, mpi-comm-platform.c:1055, hc-dist-policy.c:2208).  The engine fills
  *      per-destination send buffers with 32-byte records; the caller moves them (RCCL all-to-all over xGMI) and

@@ -1706,6 +1706,7 @@ static int scan_u32(ocrgpu_engine *e, const u32 *in, u32 *out, u64 n, u32 add0, 
     return 0;
 }
 
+static int scratch_setup(int device);
 extern "C" int ocrgpu_abi_version(void) { return 2; }
 extern "C" const char *ocrgpu_last_error(void) { return g_err; }
 
@@ -1718,6 +1719,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     if (cfg->max_edges >= (1ull << 32) || cfg->max_slots >= (1ull << 31)) FAIL(OCRGPU_EINVAL, "max_edges < 2^32 and max_slots < 2^31 per partition");
     if (cfg->location >= 1024) FAIL(OCRGPU_EINVAL, "location must fit GUID_PROVIDER_LOCID_SIZE=10 bits");
     HIPCHK(hipSetDevice(device));
+    { int sr = scratch_setup(device); if (sr) return sr; } // this GPU's address of the static scratch array (ocrgpu_pop_ready_noalloc)
     ocrgpu_engine *e = new ocrgpu_engine();
     e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
@@ -2216,7 +2218,8 @@ extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *
     return check_fault(e); // the outputs above are filled either way
 }
 
-// counters in the first 256 bytes of buf, then the five output arrays
+// Shared by ocrgpu_pop_ready (buf = the staging arena, grown on demand) and ocrgpu_pop_ready_noalloc (buf = this device's
+// copy of the static `scratch` array): counters in the first 256 bytes, then the five output arrays.
 static int pop_ready_into(ocrgpu_engine *e, char *buf, u32 r_end, u64 max_edts, u64 max_deps, u64 *n_edts_out, u64 *n_deps_out, u64 *param0_out,
                           u32 *depc_out, u32 *dep_first_out, u64 *dep_guid_out, u64 *dep_value_out) {
     size_t off = 0;
@@ -2266,6 +2269,42 @@ extern "C" int ocrgpu_pop_ready(ocrgpu_engine_t *e, u64 max_edts, u64 max_deps, 
     if (r_end <= e->pop_cursor) return 0;
     r = stage_reserve(e, 256 + rup(8 * max_edts) + 2 * rup(4 * max_edts) + 2 * rup(8 * max_deps)); if (r) return r;
     return pop_ready_into(e, e->stage_dev, r_end, max_edts, max_deps, n_edts_out, n_deps_out, param0_out, depc_out, dep_first_out, dep_guid_out, dep_value_out);
+}
+
+// ---- the entry point that allocates nothing ----------------------------------------------------------------------
+// ocrgpu_pop_ready stages its counters and its five output arrays in device memory it may have to (re)allocate.  Callers
+// that cannot allocate (a worker loop under a harness that forbids hipMalloc, code between graph captures, tight serving
+// loops) get the same call on a file-scope device array of fixed size.  Every GPU holds its own copy of the array at its own
+// address: ocrgpu_init asks for it once per device, with that device current, and host code only ever uses that pointer.
+// One array per GPU: calls that overlap on one GPU (two engines, two threads) race on it; it keeps the last call's contents.
+#define NOALLOC_MAX_EDTS 32768u
+#define NOALLOC_MAX_DEPS 131072u
+#define NOALLOC_BYTES (256u + 16u * NOALLOC_MAX_EDTS + 16u * NOALLOC_MAX_DEPS + 5u * 256u)   /* 2.5 MiB + the carve padding */
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+#define NOALLOC_MAX_DEVICES 64
+static unsigned char *g_scratch_ptr[NOALLOC_MAX_DEVICES]; // device address of `scratch` on each GPU (hipGetSymbolAddress), 0 = not asked yet
+static int scratch_setup(int device) { // called by ocrgpu_init with `device` current
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return 0; // such a device has no no-alloc entry point (it says so when called)
+    if (g_scratch_ptr[device]) return 0;
+    void *ptr = nullptr;
+    HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) FAIL(OCRGPU_EHIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+    g_scratch_ptr[device] = (unsigned char *)ptr;
+    return 0;
+}
+extern "C" int ocrgpu_pop_ready_noalloc(ocrgpu_engine_t *e, u64 max_edts, u64 max_deps, u64 *n_edts_out, u64 *n_deps_out, u64 *param0_out,
+                                        u32 *depc_out, u32 *dep_first_out, u64 *dep_guid_out, u64 *dep_value_out) {
+    ENTER(e);
+    if (max_edts > NOALLOC_MAX_EDTS || max_deps > NOALLOC_MAX_DEPS)
+        FAIL(OCRGPU_EINVAL, "ocrgpu_pop_ready_noalloc: room for %llu EDTs / %llu deps asked, the static scratch holds at most %u / %u (use ocrgpu_pop_ready)",
+             (unsigned long long)max_edts, (unsigned long long)max_deps, NOALLOC_MAX_EDTS, NOALLOC_MAX_DEPS);
+    unsigned char *ptr = (e->device >= 0 && e->device < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[e->device] : nullptr;
+    if (!ptr) FAIL(OCRGPU_ENOTSUP, "ocrgpu_pop_ready_noalloc: no scratch address for device %d", e->device);
+    u32 r_end;
+    int r = pop_ready_args(e, max_edts, max_deps, n_edts_out, n_deps_out, param0_out, depc_out, dep_first_out, dep_guid_out, dep_value_out, &r_end);
+    if (r) return r;
+    if (r_end <= e->pop_cursor) return 0;
+    return pop_ready_into(e, (char *)ptr, r_end, max_edts, max_deps, n_edts_out, n_deps_out, param0_out, depc_out, dep_first_out, dep_guid_out, dep_value_out);
 }
 
 extern "C" int ocrgpu_step_info(ocrgpu_engine_t *e, u64 *out4) {

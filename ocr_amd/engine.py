@@ -64,7 +64,7 @@ EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error
            "ocrgpu_guid_reserve", "ocrgpu_guid_put", "ocrgpu_guid_tryput", "ocrgpu_guid_get", "ocrgpu_guid_remove",
            "ocrgpu_event_create", "ocrgpu_db_create", "ocrgpu_edt_create", "ocrgpu_edt_set_scripts",
            "ocrgpu_set_hash_tag_base", "ocrgpu_add_dependence", "ocrgpu_event_satisfy_slot", "ocrgpu_event_destroy", "ocrgpu_edt_release_dbs",
-           "ocrgpu_resolve", "ocrgpu_step", "ocrgpu_step_info", "ocrgpu_pop_ready", "ocrgpu_exchange_apply_strided", "ocrgpu_exchange_config", "ocrgpu_exchange_counts",
+           "ocrgpu_resolve", "ocrgpu_step", "ocrgpu_step_info", "ocrgpu_pop_ready", "ocrgpu_pop_ready_noalloc", "ocrgpu_exchange_apply_strided", "ocrgpu_exchange_config", "ocrgpu_exchange_counts",
            "ocrgpu_exchange_reset", "ocrgpu_exchange_apply", "ocrgpu_snapshot", "ocrgpu_restore", "ocrgpu_sync", "ocrgpu_read_edts",
            "ocrgpu_read_events", "ocrgpu_read_dbs", "ocrgpu_read_fired", "ocrgpu_get_stats"]
 
@@ -191,6 +191,16 @@ class Engine:
         self._chk(self.lib.ocrgpu_edt_create(self.h, C.c_uint64(n), _ptr(depc), _ptr(body), _ptr(param0), _ptr(g),
                                              _ptr(oe), _ptr(od), HOST))
         return g, oe, od
+
+    def pop_ready_noalloc(self, max_edts=32768, max_deps=131072):
+        """ocrgpu_pop_ready_noalloc: the same hand-over on the library's static device scratch (no allocation; the
+        capacities are bounded by it and a larger request is refused)."""
+        p0, dc, df = np.empty(max_edts, np.uint64), np.empty(max_edts, np.uint32), np.empty(max_edts, np.uint32)
+        dg, dv = np.empty(max_deps, np.uint64), np.empty(max_deps, np.uint64)
+        ne, nd = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.lib.ocrgpu_pop_ready_noalloc(self.h, C.c_uint64(max_edts), C.c_uint64(max_deps), C.byref(ne), C.byref(nd),
+                                                    _ptr(p0), _ptr(dc), _ptr(df), _ptr(dg), _ptr(dv)))
+        return p0[:ne.value], dc[:ne.value], df[:ne.value], dg[:nd.value], dv[:nd.value]
 
     def pop_ready(self, max_edts=1 << 16, max_deps=1 << 18):
         """EDTs with OCRBODY_HOST bodies that fired since the last call: (param0[n], depc[n], dep_first[n],
