@@ -58,12 +58,6 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_
 // count in bits 0..28 and mark the (always stored, never pre-filled) overflow slot words.
 #define PEND_INL_CNT 0xFFu
 #define PEND_INL_BIT(k) (0x100u << (k))
-// Fire info of an EDT, kept beside every waiter record that names it and handed on through the ready log, so that the FIRE
-// pass can start the EDT's fan-out without reading its line: {out_row, fi}; fi = FI_FAST | FI_OUTEVT | FI_OUTDB | out_deg.
-#define FI_FAST 0x80000000u   // the entry is valid: built-in HASH / NOP body, no script, row no longer than BIG_ROW
-#define FI_OUTDB 0x40000000u  // the body returns its own output datablock (HASH); else NULL_GUID (NOP)
-#define FI_OUTEVT 0x20000000u // the EDT has a ONCE output event (else out_deg = 0)
-#define FI_DEG 0x0000FFFFu
 #define LAZY_FRONT 0xFFFFFFFFu // lazy_tab key slot of an EDT's frontier word
 #define CNT_SAT (1ull << 63)   // counted[]: [satisfied:1 | registrations left:31 | lazy registrations not yet made:32]
 #define BODY_F_SCRIPT 0x10000u // internal: EDT has a script
@@ -150,14 +144,12 @@ struct Dev {
                                 // CHANNEL events: satisfies so far << 32 | registrations so far
     ChanRec *chan; u32 *chan_sat; u32 chan_sat_cap; // CHANNEL events: evt[x].val = index into chan[]
     ulonglong2 *lazy_tab; u64 lazy_mask; // (EDT, pre-slot) -> COUNTED event waiting for the frontier; (EDT, LAZY_FRONT) -> frontier
-    ulonglong2 *waiters;        // CSR payload, 16 B: x.lo = dst ; x.hi = flags<<28 | (pre-slot k of the EDT | latch slot);
-                                // y = fire info of an EDT destination {out_row, fi} (0 = none: the FIRE pass reads the EDT's line)
+    u64 *waiters;               // CSR payload: lo = dst ; hi = flags<<28 | (pre-slot k of the EDT | latch slot)
     u32 *log_src; u64 *log_rec; // registration log the CSR is built from
     // datablocks (explicit [0,max_db) then the output DB of EDT e at max_db+e): {value, tag}
     ulonglong2 *db;
     // work lists
     u32 *fired;                 // fired/ready log, grouped by level
-    u64 *fired_aux;             // beside every valid entry of `fired`: the EDT's fire info {out_row, fi} or 0
     u32 *level_start;           // level_start[L] = offset in `fired`
     Rec *q;                     // satisfy-record log
     u64 *blk_stats;             // [MAX_GRID][4] per-workgroup counters (no atomics): edt_sat, evt_sat, fired
@@ -302,16 +294,16 @@ __device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, const Step &S, u3
     EdtLine *L = &d.edt[edt];
     u32 word = (flags & RF_MODE_NULL) ? 0u : payload;
     // overflow pre-slots (depc > 6): `slot` is relative, the base sits in the line the atomic is about to touch
-    u32 *sp = nullptr;
-    if (NANNY || !(flags & RF_PREFILLED)) sp = (flags & RF_INLINE) ? &L->slot[slot] : &d.slots[(size_t)L->slot[0] + slot];
+    const bool inl = (flags & RF_INLINE) != 0;
     if (NANNY) {
+        u32 *sp = inl ? &L->slot[slot] : &d.slots[(size_t)L->slot[0] + slot];
         u32 old = atomicExch(sp, word | SLOT_MARK);
         if (old & SLOT_MARK) { atomicAdd(&d.ctrl->err[ERR_DOUBLE_SLOT], 1u); return false; }
-    } else if (!(flags & RF_PREFILLED)) {
-        *sp = word | SLOT_MARK;
     }
-    const bool inl = (flags & RF_INLINE) != 0;
     const u32 old = atomicAdd(&L->pending, inl ? PEND_INL_BIT(slot) - 1u : 0xFFFFFFFFu); // count down (+ mark, inline pre-slots)
+    // The payload word goes out BEHIND the atomic: an overflow pre-slot's address needs the base from the destination's line, and
+    // that load must not stand in front of the whole wave's atomics (the word is only read after the next kernel boundary)
+    if (!NANNY && !(flags & RF_PREFILLED)) *(inl ? &L->slot[slot] : &d.slots[(size_t)L->slot[0] + slot]) = word | SLOT_MARK;
     const u32 left = old & (inl ? PEND_INL_CNT : PEND_MASK);
     if (old & PEND_LAZY) { // rare: this EDT's frontier is tracked (COUNTED accounting); the walk runs in the next EVENTS phase
         const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
@@ -325,6 +317,34 @@ __device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, const Step &S, u3
         return false;
     }
     return left == 1u;
+}
+// An EDT with more than 6 pre-slots whose frontier starts being tracked (a COUNTED source arrives on a later pre-slot): its
+// pre-filled pre-slots were satisfied by bare counter decrements and carry no mark.  If the unmarked pre-slots outnumber the
+// unsatisfied ones, the difference are such pre-slots: they are found through the registration log (destination = this EDT,
+// pre-filled, source event no longer live) and marked, provided exactly that many qualify.  Rare path, one thread.
+__device__ void mark_prefilled_overflow(const Dev &d, u32 didx) {
+    EdtLine *L = &d.edt[didx];
+    const u32 depc = L->depc;
+    if (depc <= INLINE_SLOTS) return;
+    u32 *sl = d.slots + L->slot[0];
+    u32 unmarked = 0;
+    for (u32 k = 0; k < depc; ++k) unmarked += (atomicOr(&sl[k], 0u) & SLOT_MARK) ? 0u : 1u;
+    const u32 left = atomicOr(&L->pending, 0u) & PEND_MASK;
+    if (unmarked <= left) return;
+    u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
+    for (int pass = 0; pass < 2; ++pass) { // count the candidates, then mark them if they are exactly the missing ones
+        u32 cand = 0;
+        for (u32 i = 0; i < n; ++i) {
+            const u64 rec = d.log_rec[i];
+            const u32 hi = (u32)(rec >> 32), fl = hi >> 28;
+            if ((u32)rec != didx || (fl & (RF_DST_EDT | RF_PREFILLED | RF_INLINE)) != (RF_DST_EDT | RF_PREFILLED)) continue;
+            const u32 st = *evt_state(d, d.log_src[i]) & 0xFF;
+            if (st != ST_DESTROYED && st != ST_SAT) continue;
+            u32 *w = &sl[hi & 0x0FFFFFFFu];
+            if (pass == 0) cand += (atomicOr(w, 0u) & SLOT_MARK) ? 0u : 1u; else atomicOr(w, SLOT_MARK);
+        }
+        if (pass == 0 && cand != unmarked - left) return;
+    }
 }
 // has pre-slot f of this EDT been satisfied?  (frontier walks; reads through returning atomics: other CUs write these words)
 __device__ __forceinline__ bool slot_satisfied(EdtLine *L, u32 *sl, u32 depc, u32 f) {
@@ -622,13 +642,12 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         u32 t = base + threadIdx.x;
         bool act = t < total;
         bool ready = false, to_evt = false, is_latch = false;
-        u32 dst = 0, slot = 0, payload = 0, flags = 0, kind = 0; u64 finfo = 0;
+        u32 dst = 0, slot = 0, payload = 0, flags = 0, kind = 0;
         if (act) {
             u32 lo = 0, hi = nseg - 1; // first segment with end_off > t
             while (lo < hi) { u32 mid = (lo + hi) >> 1; if (seg[mid].end_off > t) hi = mid; else lo = mid + 1; }
             u32 start = lo ? seg[lo - 1].end_off : 0;
-            const ulonglong2 w2 = d.waiters[seg[lo].row + (t - start)]; // one 16-B load: the edge and its destination's fire info
-            const u64 w = w2.x; finfo = w2.y;
+            const u64 w = d.waiters[seg[lo].row + (t - start)];
             u32 whi = (u32)(w >> 32);
             dst = (u32)w; flags = whi >> 28; slot = whi & 0x0FFFFFFFu; payload = seg[lo].payload;
             if (flags & RF_DST_EDT) ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, dst, slot, payload, flags);
@@ -642,10 +661,7 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         // statistics are wave totals (one ballot each), so the epilogue needs no cross-lane reduction
         n_edt_sat += __popcll(__ballot(act && (flags & RF_DST_EDT))); n_evt_sat += __popcll(__ballot(to_evt));
         if (base == 0) { if (threadIdx.x == 0) *lds_base = rbase; lds_barrier(); rbase = *lds_base; }
-        if (act) {
-            if (rbase + t < d.fired_cap) { d.fired[rbase + t] = ready ? dst : INVALID; if (ready) d.fired_aux[rbase + t] = finfo; }
-            else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
-        }
+        if (act) { if (rbase + t < d.fired_cap) d.fired[rbase + t] = ready ? dst : INVALID; else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u); }
         // event -> event dependences: run the destination's satisfy logic right here (commonSatisfyRegNode
         // recursing into processMessage, hc-event.c:335-367); only an event that FIRES costs a queue record
         if (__ballot(to_evt)) {
@@ -717,7 +733,6 @@ __device__ void deferred_bodies(const Dev &d, u32 b_begin, u32 b_end, u32 h, u32
         if (e == INVALID) continue;
         const EdtLine L = d.edt[e];
         if (OCRBODY_KIND(L.body) == OCRBODY_HOST) continue;
-        if ((L.body & OCRBODY_F_OUTEVT) && (L.out_state & 0xFF) == ST_LIVE) d.edt[e].out_state = ST_DESTROYED | (OCREVT_ONCE << 8); // fired on the fast path
         const u32 *sl; u32 pw[8]; ulonglong2 gb[8];
         if (L.depc <= INLINE_SLOTS) {
 #pragma unroll
@@ -851,23 +866,12 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             // Critical path per level: ready-log entry -> the EDT's 64-B line -> waiter row -> atomicSub -> log store.
             // The body's gathers (the DBs named by the pre-slot words, which sit in the same line) are issued
             // BEFORE the fan-out and consumed after it, so they ride under it.
-            u32 e = INVALID; u64 aux = 0;
-            if (i < S.r_end) { e = d.fired[i]; aux = d.fired_aux[i]; } // both coalesced; aux of a hole is never looked at
+            u32 e = INVALID;
+            if (i < S.r_end) e = d.fired[i];
             const bool mine = e != INVALID;
             bool epi = false;
             u32 body = 0, depc = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr; ulonglong2 gb[8];
-            // Fast path (plain single-partition run, bodies deferred): the ready-log entry carries the EDT's fire info, handed
-            // on by the satisfier from the waiter record it had just read, so the fan-out starts from the entry itself and the
-            // critical path of a level is entry -> waiter row -> atomic -> entry: the EDT's line is not read here at all (the
-            // deferred body reads it one launch later, off the path).  The output event is marked destroyed with a blind store.
-            const u32 fi = (u32)(aux >> 32);
-            const bool fast = !NANNY && !LOCKABLE && defer && mine && (fi & FI_FAST);
-            if (fast) {
-                if (fi & FI_OUTEVT) { // satisfyEventHcOnce: fires, then destroys itself -- the state word is written by the deferred body,
-                    epi = true;       // which touches the line anyway (nothing reads it before the run's bodies are paid)
-                    deg = fi & FI_DEG; sg.row = (u32)aux; sg.payload = (fi & FI_OUTDB) ? d.max_db + e + 1 : 0u;
-                }
-            } else if (mine) {
+            if (mine) {
                 const EdtLine L = d.edt[e]; // the one 64-B read that carries everything this EDT needs to fire
                 body = L.body; depc = L.depc; id = L.param0;
                 const u32 x = d.max_evt + e;
@@ -938,7 +942,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             STAMP(2);
             if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             STAMP(3);
-            if (mine && !fast && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST) run_body(d, e, id, depc, sl, gb);
+            if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST) run_body(d, e, id, depc, sl, gb);
         }
     } else {
         // ---- queued satisfies: API calls, fired chained events, big-row pieces, direct EDT pre-slot satisfies ----
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             }
             n_edt_sat += __popcll(__ballot(cnt_edt)); n_evt_sat += __popcll(__ballot(cnt_evt));
             u32 ri = S.r_base + wave_append(S.cnt_r, ready);
-            if (ready) { d.fired[ri] = r.dst; d.fired_aux[ri] = 0ull; }
+            if (ready) d.fired[ri] = r.dst;
             bool fire = latch_group(d, is_latch, r.dst, r.slot);
             if (act && (r.flags & RF_CHANGEN)) { deg = 1; sg.row = r.slot; sg.payload = r.payload; } // a CHANNEL pairing made in a fan-out
             else if (act && (r.flags & RF_FIRED)) fire = true;
@@ -1119,7 +1123,7 @@ __global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, con
         gtab_put(d, gd, (u64)(d.max_db + e) + 1);
         if (outdb_out) outdb_out[i] = gd;
     }
-    if (dc == 0) { u32 ri = atomicAdd(&d.ctrl->r_tail, 1u); d.fired[ri] = e; d.fired_aux[ri] = 0ull; } // fires at creation (hc-task.c:1129-1134)
+    if (dc == 0) { u32 ri = atomicAdd(&d.ctrl->r_tail, 1u); d.fired[ri] = e; } // fires at creation (hc-task.c:1129-1134)
 }
 
 __device__ __forceinline__ void q_push(const Dev &d, Rec r) {
@@ -1156,7 +1160,7 @@ __device__ __forceinline__ bool chan_register(const Dev &d, u32 x, u64 waiter, u
     const u32 k = (u32)old, ns = (u32)(old >> 32);
     if (k < ns) { payload = d.chan_sat[c.sat_base + k % c.cap]; return true; }
     if (k - ns >= c.cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return false; } // more than maxGen waiters in line (ASSERT :2005)
-    d.waiters[c.wait_base + k % c.cap] = make_ulonglong2(waiter, 0ull);
+    d.waiters[c.wait_base + k % c.cap] = waiter;
     return false;
 }
 
@@ -1227,6 +1231,7 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
         // the data path registers now, the COUNT waits for the frontier (registerSignalerTaskHc hc-task.c:1391-1405)
         EdtLine *L = &d.edt[didx];
         u32 *sl = (dflag & RF_INLINE) ? L->slot : d.slots + L->slot[0];
+        if (!(dflag & RF_INLINE) && !(L->pending & PEND_LAZY)) mark_prefilled_overflow(d, didx);
         u32 f = 0;
         while (f < slot[i] && slot_satisfied(L, sl, L->depc, f)) ++f;
         if (f < slot[i]) {
@@ -1257,8 +1262,11 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
             if (bk == OCRBODY_HASH) { known = true; word = d.max_db + se + 1; }
             else if (bk == OCRBODY_NOP) known = true;
         }
-        // inline pre-slots only: their satisfied mark rides in the pending word; an overflow word is marked by the satisfy's store
-        if (known && (dflag & RF_INLINE)) { pre = RF_PREFILLED; d.edt[didx].slot[dslot] = word; }
+        // The satisfied mark of an inline pre-slot rides in the pending word; pre-filled OVERFLOW pre-slots have none until
+        // the EDT's frontier is tracked -- mark_prefilled_overflow() recovers theirs from the registration log when it matters.
+        // (an overflow pre-slot too: a satisfy that had to store there would first have to fetch the base from the destination's
+        // line, in front of its wave's atomics -- 2.7 % of config 2's edges cost 4 % of a level that way)
+        if (known) { pre = RF_PREFILLED; *((dflag & RF_INLINE) ? &d.edt[didx].slot[dslot] : &d.slots[(size_t)d.edt[didx].slot[0] + dslot]) = word; }
     }
     u32 li = atomicAdd(&d.ctrl->log_tail, 1u);
     if ((u64)li + d.ctrl->chan_wait_used >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // waiters[] top end = CHANNEL rings
@@ -1383,6 +1391,7 @@ __device__ void apply_record(const Dev &d, const SendRec &r, u32 db_floor) {
         if (!(dflag & RF_DST_EDT)) { bad_op(d); return; }
         EdtLine *L = &d.edt[didx];
         u32 *sl = (dflag & RF_INLINE) ? L->slot : d.slots + L->slot[0];
+        if (!(dflag & RF_INLINE) && !(L->pending & PEND_LAZY)) mark_prefilled_overflow(d, didx);
         u32 f = 0;
         while (f < r.slot && slot_satisfied(L, sl, L->depc, f)) ++f;
         if (f < r.slot) {
@@ -1476,25 +1485,8 @@ __global__ void k_csr_fill(Dev d, u32 *cursor) {
     u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         u32 x = d.log_src[i];
-        if ((*evt_state(d, x) & 0xFF) != ST_LIVE) continue;
-        const u64 rec = d.log_rec[i];
-        u64 finfo = 0;
-        if (((u32)(rec >> 32) >> 28) & RF_DST_EDT) { // the destination's own fan-out, known now that every row has its place
-            const EdtLine *L = &d.edt[(u32)rec];
-            const u32 body = L->body, kind = OCRBODY_KIND(body);
-            if ((kind == OCRBODY_HASH || kind == OCRBODY_NOP) && !(body & BODY_F_SCRIPT)) {
-                if (!(body & OCRBODY_F_OUTEVT)) finfo = (u64)FI_FAST << 32;
-                else if (L->out_deg <= BIG_ROW)
-                    finfo = ((u64)(FI_FAST | FI_OUTEVT | (kind == OCRBODY_HASH ? FI_OUTDB : 0u) | L->out_deg) << 32) | L->out_row;
-            }
-        }
-        d.waiters[atomicAdd(&cursor[x], 1u)] = make_ulonglong2(rec, finfo);
+        if ((*evt_state(d, x) & 0xFF) == ST_LIVE) d.waiters[atomicAdd(&cursor[x], 1u)] = d.log_rec[i];
     }
-}
-// a re-seal moved the rows: ready-log entries waiting to fire forget the fire info they carry (the FIRE pass reads the line)
-__global__ void k_ready_aux_clear(Dev d) {
-    const u32 b = d.ctrl->r_end, n = d.ctrl->r_tail;
-    for (u32 i = b + blockIdx.x * blockDim.x + threadIdx.x; i < n && i < d.fired_cap; i += gridDim.x * blockDim.x) d.fired_aux[i] = 0ull;
 }
 
 // ---- exclusive scan (u32), 1024 elements per workgroup, recursive over the partials -------------------
@@ -1597,12 +1589,12 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); return OCRGPU_EHIP; } } while (0)
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
-struct Snapshot { DbLock *dbl; EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; ulonglong2 *chan_wait; u32 *chan_sat; u32 chan_wait_used, chan_sat_used; u32 *fired; u64 *fired_aux; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries;
+struct Snapshot { DbLock *dbl; EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; u64 *chan_wait; u32 *chan_sat; u32 chan_wait_used, chan_sat_used; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries;
                   u64 edges_upper, seal_epoch, err_seen; bool valid; };
 static void snap_free(Snapshot &s) {
     if (s.dbl) (void)hipFree(s.dbl);
     s.dbl = nullptr;
-    (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.counted); (void)hipFree(s.lazy_tab); (void)hipFree(s.slots); (void)hipFree(s.chan_wait); (void)hipFree(s.chan_sat); (void)hipFree(s.fired); (void)hipFree(s.fired_aux); (void)hipFree(s.ctrl);
+    (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.counted); (void)hipFree(s.lazy_tab); (void)hipFree(s.slots); (void)hipFree(s.chan_wait); (void)hipFree(s.chan_sat); (void)hipFree(s.fired); (void)hipFree(s.ctrl);
     s.valid = false;
 }
 
@@ -1761,7 +1753,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
         d.lazy_mask = lc - 1; e->lazy_cap = lc;
         TRY(dalloc(e, (void **)&d.lazy_tab, 16 * (size_t)lc));
     }
-    TRY(dalloc(e, (void **)&d.waiters, 16 * (size_t)d.max_edges));
+    TRY(dalloc(e, (void **)&d.waiters, 8 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.log_src, 4 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.log_rec, 8 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.db, 16 * (size_t)n_db_total));
@@ -1772,7 +1764,6 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     u64 fired_cap = (u64)cfg->max_edt + d.max_edges + 4096; if (fired_cap > 0xFFFFFFF0ull) fired_cap = 0xFFFFFFF0ull;
     e->fired_cap = fired_cap; d.fired_cap = (u32)fired_cap;
     TRY(dalloc(e, (void **)&d.fired, 4 * (size_t)fired_cap, false));
-    TRY(dalloc(e, (void **)&d.fired_aux, 8 * (size_t)fired_cap, false));
     TRY(dalloc(e, (void **)&d.level_start, 4 * ((size_t)d.max_levels + 2)));
     TRY(dalloc(e, (void **)&d.q, sizeof(Rec) * (size_t)q_cap, false));
     TRY(dalloc(e, (void **)&d.blk_stats, 8 * 4 * MAX_GRID));
@@ -1863,7 +1854,6 @@ static int seal(ocrgpu_engine *e) {
     if (r) return r;
     k_csr_set_rows<<<nblk(used), 256, 0, e->stream>>>(d, used, e->tmp_b, e->tmp_c);
     k_csr_fill<<<g, 256, 0, e->stream>>>(d, e->tmp_c);
-    k_ready_aux_clear<<<64, 256, 0, e->stream>>>(d);
     HIPCHK(hipGetLastError());
     e->csr_dirty = false; ++e->seal_epoch;
     return 0;
@@ -2083,7 +2073,6 @@ extern "C" int ocrgpu_edt_set_scripts(ocrgpu_engine_t *e, u64 n, const u64 *edt,
     k_script_merge_latch<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dbg, dl, (u32)e->n_script);
     k_set_scripts<<<nblk(n), 256, 0, e->stream>>>(e->d, n, de, dbg, dl, (u32)e->n_script);
     e->n_script += n_ops;
-    e->csr_dirty = true; // a scripted EDT fires through its line, not through fire info sealed into waiter records
     HIPCHK(hipGetLastError());
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
@@ -2415,12 +2404,11 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     s.chan_wait_used = e->pinned_done[33014]; s.chan_sat_used = e->pinned_done[33015]; // CHANNEL rings in use
     if (s.chan_wait_used > d.max_edges) s.chan_wait_used = (u32)d.max_edges;
     if (s.chan_sat_used > d.chan_sat_cap) s.chan_sat_used = d.chan_sat_cap;
-    HIPCHK(hipMalloc((void **)&s.chan_wait, 16 * (size_t)s.chan_wait_used + 64));
+    HIPCHK(hipMalloc((void **)&s.chan_wait, 8 * (size_t)s.chan_wait_used + 64));
     HIPCHK(hipMalloc((void **)&s.chan_sat, 4 * (size_t)s.chan_sat_used + 64));
-    if (s.chan_wait_used) HIPCHK(hipMemcpyAsync(s.chan_wait, d.waiters + (d.max_edges - s.chan_wait_used), 16 * (size_t)s.chan_wait_used, hipMemcpyDeviceToDevice, e->stream));
+    if (s.chan_wait_used) HIPCHK(hipMemcpyAsync(s.chan_wait, d.waiters + (d.max_edges - s.chan_wait_used), 8 * (size_t)s.chan_wait_used, hipMemcpyDeviceToDevice, e->stream));
     if (s.chan_sat_used) HIPCHK(hipMemcpyAsync(s.chan_sat, d.chan_sat, 4 * (size_t)s.chan_sat_used, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMalloc((void **)&s.fired, 4 * (size_t)s.n_fired_entries + 16));
-    HIPCHK(hipMalloc((void **)&s.fired_aux, 8 * (size_t)s.n_fired_entries + 16));
     HIPCHK(hipMalloc((void **)&s.ctrl, sizeof(Ctrl)));
     s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt; s.n_db = e->n_db; e->snap_pop_cursor = e->pop_cursor;
     s.edges_upper = e->edges_upper; s.seal_epoch = e->seal_epoch; s.err_seen = e->err_seen;
@@ -2430,7 +2418,6 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     HIPCHK(hipMemcpyAsync(s.lazy_tab, d.lazy_tab, 16 * (size_t)e->lazy_cap, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_slots) HIPCHK(hipMemcpyAsync(s.slots, d.slots, 4 * (size_t)s.n_slots, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(s.fired, d.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
-    if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(s.fired_aux, d.fired_aux, 8 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(s.ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
     return 0;
 }
@@ -2452,12 +2439,11 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     HIPCHK(hipMemcpyAsync(d.evt, s.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     if (e->n_evt) HIPCHK(hipMemcpyAsync(d.counted, s.counted, 8 * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.lazy_tab, s.lazy_tab, 16 * (size_t)e->lazy_cap, hipMemcpyDeviceToDevice, e->stream));
-    if (s.chan_wait_used) HIPCHK(hipMemcpyAsync(d.waiters + (d.max_edges - s.chan_wait_used), s.chan_wait, 16 * (size_t)s.chan_wait_used, hipMemcpyDeviceToDevice, e->stream));
+    if (s.chan_wait_used) HIPCHK(hipMemcpyAsync(d.waiters + (d.max_edges - s.chan_wait_used), s.chan_wait, 8 * (size_t)s.chan_wait_used, hipMemcpyDeviceToDevice, e->stream));
     if (s.chan_sat_used) HIPCHK(hipMemcpyAsync(d.chan_sat, s.chan_sat, 4 * (size_t)s.chan_sat_used, hipMemcpyDeviceToDevice, e->stream));
     // pre-slot words carry the "satisfied" marks: overflow words go back to what they were (inline ones are in the lines)
     if (s.n_slots) HIPCHK(hipMemcpyAsync(d.slots, s.slots, 4 * (size_t)s.n_slots, hipMemcpyDeviceToDevice, e->stream));
     if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(d.fired, s.fired, 4 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
-    if (s.n_fired_entries) HIPCHK(hipMemcpyAsync(d.fired_aux, s.fired_aux, 8 * (size_t)s.n_fired_entries, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.ctrl, s.ctrl, sizeof(Ctrl), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemsetAsync(d.blk_stats, 0, 8 * 4 * MAX_GRID, e->stream)); // statistics restart with the re-armed DAG
     return 0;

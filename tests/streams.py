@@ -174,7 +174,19 @@ def counted_after_null_preslot():
     g = b.edt(1, BODY_NOP)
     b.add_dep(start, g, 0, MODE_RO)
     b.script_satisfy(g, y, 0)              # ... until level 0 satisfies pre-slot 0: frontier reaches 2, counted, destroyed
-    return b.finish([e0, e1, g], start)
+    # the same on an EDT with more than 6 pre-slots (their words live outside the EDT's line): pre-slots 0..6 are satisfied by
+    # DB_MODE_NULL events before the COUNTED source on pre-slot 7 exists; pre-slot 8 comes later
+    e2 = b.edt(9)
+    zs = [b.evt(EVT_ONCE) for _ in range(7)]
+    for k, z in enumerate(zs):
+        b.add_dep(z, e2, k, MODE_NULL)
+    for z in zs:
+        b.satisfy(z, 0)
+    c2 = b.evt(EVT_COUNTED, 1)
+    b.add_dep(c2, e2, 7, MODE_RO)          # the frontier stands at 7: counted at once
+    b.satisfy(c2, d)
+    b.add_dep(start, e2, 8, MODE_RO)
+    return b.finish([e0, e1, g, e2], start)
 
 
 def idem_double_satisfy():
