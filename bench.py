@@ -66,8 +66,6 @@ def main():
 
     from ocr_amd import engine, opstream
     if world > 1:
-        if backend == "nccl":
-            backend = collectives_selftest(torch, dist, local)
         return main_partitioned(args, torch, dist, rank, world, local, backend)
 
     # ---- build: every rank owns one partition = one independent layered DAG (seeded per rank) ----
@@ -216,45 +214,38 @@ def launch_ranks(n):
     return 0
 
 
-def collectives_selftest(torch, dist, local):
-    """Create the RCCL group and run the collectives the exchange uses on it (count all-to-all, ragged uint8
-    all-to-all-v with empty splits, equal-split all-to-all, int64 all-gather), checked for content.  The verdict is
-    agreed over the gloo default group: RCCL is used only if EVERY rank passed (ocr_amd.distributed.DEV_GROUP)."""
-    import sys
-    from ocr_amd import distributed as D
-    W, r = dist.get_world_size(), dist.get_rank()
-    dev = torch.device("cuda", local)
-    ok, why, g = 1, "", None
+def c_transport_up(part, torch, dist, rank, world):
+    """Bring up libocrgpu's own RCCL communicator (ocrgpu_comm_init: one rank per engine) and run one content-checked
+    all-to-all and one empty exchange round on it.  The verdict is agreed over the gloo default group: the C transport is
+    used only if EVERY rank passed; otherwise the exchange stays on gloo with host-staged records."""
+    from ocr_amd import engine
+    ok, why = 1, ""
+    devs = [None] * world
+    dist.all_gather_object(devs, torch.cuda.current_device())
+    if len(set(devs)) < world:                               # RCCL wants one device per rank: do not even try (it may not return)
+        if rank == 0:
+            print(f"[bench] {world} ranks on devices {devs}: ranks share a GPU, the exchange stays on gloo", file=sys.stderr)
+        return False
+    uid = [engine.comm_get_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)                   # 128 bytes over gloo: the out-of-band channel
     try:
-        g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
-        out_counts = [(r + d) % 3 for d in range(W)]
-        cnt_out = torch.tensor(out_counts, dtype=torch.int64, device=dev)
-        cnt_in = torch.empty_like(cnt_out)
-        dist.all_to_all_single(cnt_in, cnt_out, group=g)
-        cin = [int(x) for x in cnt_in.cpu().tolist()]
-        assert cin == [(s + r) % 3 for s in range(W)], cin
-        send = torch.full((sum(out_counts), 32), r, dtype=torch.uint8, device=dev)
-        recv = torch.empty((sum(cin), 32), dtype=torch.uint8, device=dev)
-        dist.all_to_all_single(recv, send, output_split_sizes=cin, input_split_sizes=out_counts, group=g)
-        want = torch.cat([torch.full((cin[s], 32), s, dtype=torch.uint8) for s in range(W)]) if sum(cin) else recv.cpu()
-        assert torch.equal(recv.cpu(), want)
-        eq_s = torch.full((W, 3, 32), r, dtype=torch.uint8, device=dev)
-        eq_r = torch.empty_like(eq_s)
-        dist.all_to_all_single(eq_r.view(-1), eq_s.view(-1), group=g)
-        assert [int(eq_r[s, 0, 0]) for s in range(W)] == list(range(W))
-        rows = [torch.empty_like(cnt_out) for _ in range(W)]
-        dist.all_gather(rows, cnt_out, group=g)
-        assert [int(x[0]) for x in rows] == [s % 3 for s in range(W)]
-        torch.cuda.synchronize()
-    except Exception as ex:  # noqa: BLE001 -- whatever RCCL refuses
+        part.eng.comm_init(uid[0], rank, world)
+        src = (torch.arange(world * 1024, dtype=torch.int64, device="cuda") + 1_000_000 * rank)
+        dst = torch.zeros_like(src)
+        part.eng.comm_alltoall(src.data_ptr(), dst.data_ptr(), 1024 * 8)
+        part.eng.sync()
+        want = torch.cat([torch.arange(rank * 1024, (rank + 1) * 1024, dtype=torch.int64) + 1_000_000 * p for p in range(world)])
+        assert torch.equal(dst.cpu(), want), "all-to-all content"
+        rin, act, sent, queued = part.eng.exchange()
+        assert (rin, sent) == (0, 0), (rin, sent)
+    except Exception as ex:  # noqa: BLE001 -- whatever RCCL refuses (e.g. two ranks on one device in a rehearsal)
         ok, why = 0, f"{type(ex).__name__}: {str(ex)[:300]}"
     verdict = torch.tensor([ok], dtype=torch.int64)
-    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)          # gloo: every rank learns whether all of them passed
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
     if int(verdict.item()) == 1:
-        D.DEV_GROUP = g
-        return "nccl"
-    print(f"[bench] rank {r}: RCCL group unusable ({why or 'another rank failed'}); the exchange stays on gloo", file=sys.stderr)
-    return "gloo"
+        return True
+    print(f"[bench] rank {rank}: RCCL transport unusable ({why or 'another rank failed'}); the exchange stays on gloo", file=sys.stderr)
+    return False
 
 
 def main_partitioned(args, torch, dist, rank, world, local, backend):
@@ -276,6 +267,10 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     part = LayeredPartition(N, width, rank, world, device=local, flags=engine.F_TIMING, allreduce_sum=allreduce_sum)
     part.build()
     distributed_exchange(part, dist)             # deliver what construction sent across (nothing for this DAG)
+    # the per-level loop and the exchange run in C over libocrgpu's own RCCL communicator (ocrgpu_resolve_exchange); when
+    # RCCL cannot come up (a rehearsal with several ranks on one GPU) the same protocol runs from Python over gloo
+    use_c = backend == "nccl" and c_transport_up(part, torch, dist, rank, world)
+    backend = "RCCL, C transport: ocrgpu_resolve_exchange" if use_c else "gloo, host-staged records"
     part.eng.snapshot()
     part.eng.sync()
     build_s = time.time() - t0
@@ -283,6 +278,8 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     def step():
         part.eng.restore()
         part.satisfy_start()
+        if use_c:
+            return part.eng.resolve_exchange(no_cascade=True)
         return resolve_distributed(part, dist)
 
     def fence():

@@ -248,6 +248,52 @@ int ocrgpu_exchange_apply(ocrgpu_engine_t *e, const void *records, uint64_t n, i
 int ocrgpu_exchange_apply_strided(ocrgpu_engine_t *e, const void *records_dev, uint32_t n_src, uint64_t stride_records,
                                   const uint32_t *counts);
 
+/* ---- the comm-platform itself, over RCCL (replaces ocrCommPlatformFcts_t switchRunlevel / sendMessage / pollMessage of
+ *      ocr/src/comm-platform/mpi/mpi-comm-platform.c: MPI_Init :54 -> ocrgpu_comm_init, MPI_Isend of one marshalled
+ *      ocrPolicyMsg_t per satisfy :1055 + MPI_Iprobe / MPI_Irecv :287,620-642 -> ONE equal-split all-to-all of the send regions
+ *      per level, MPI_Finalize :60 -> ocrgpu_comm_fini; interface ocr/src/inc/ocr-comm-platform.h:55-199).  librccl is opened
+ *      with dlopen by the first of these calls; libocrgpu does not link it. -------------------------------------------------- */
+/* rank 0 makes the 128-byte id (ncclGetUniqueId); the caller hands it to every rank by whatever channel it has */
+int ocrgpu_comm_get_unique_id(void *id128_out);
+/* one communicator rank per engine: rank == the engine's location, nranks == n_locations of ocrgpu_exchange_config (which comes
+ * first).  Collective: every rank calls it. */
+int ocrgpu_comm_init(ocrgpu_engine_t *e, const void *id128, int rank, int nranks);
+int ocrgpu_comm_fini(ocrgpu_engine_t *e);
+/* the transport alone (grouped ncclSend / ncclRecv on the engine's stream): bytes_per_peer bytes from region p of send_dev to
+ * rank p, region p of recv_dev from rank p.  Asynchronous: ocrgpu_sync() or a later call on the engine waits for it. */
+int ocrgpu_comm_alltoall(ocrgpu_engine_t *e, const void *send_dev, void *recv_dev, uint64_t bytes_per_peer);
+/* One exchange round after ocrgpu_step: headers into the last record slot of every send region {records for that destination,
+ * activity = ready-log entries fired + records sent, records sent, satisfies still queued}, the all-to-all of the regions, the
+ * apply of what arrived (counts read from the headers ON THE DEVICE), the send counters cleared -- all on the engine's stream,
+ * one synchronisation at the end.  Outputs (any may be NULL): records this partition received, and the sums over ALL
+ * partitions of activity / records sent / satisfies queued, which is what a lockstep driver needs to decide what comes next.
+ * Needs records_per_dest - 1 >= the records one step queues for one destination (a fuller region is an err[5] overflow). */
+int ocrgpu_exchange(ocrgpu_engine_t *e, uint64_t *records_in_out, uint64_t *activity_out, uint64_t *sent_out, uint64_t *queued_out);
+/* the same round for the n partitions of ONE process on one GPU (locations 0..n-1 in order): device-to-device copies in place
+ * of RCCL; how the single-GPU tests run the protocol */
+int ocrgpu_exchange_local(ocrgpu_engine_t **engines, uint32_t n, uint64_t *activity_out, uint64_t *sent_out, uint64_t *queued_out);
+/* The worker loop across partitions (hc-dist's role for this path, hc-dist-policy.c:1027-1031,2208): settle what the main
+ * program sent, then per level {ocrgpu_step(1 level, forced), exchange, settle} until no partition fired or sent anything.  Levels
+ * are closed everywhere before the next one fires: the record equals the single-partition one.  Collective over the
+ * communicator.  OCRGPU_RX_NO_CASCADE: no satisfy that arrives from another partition ever sends one on (no event -> remote
+ * waiter chains), so one exchange per level settles it (two host synchronisations per level: the step's, the exchange's).
+ * OCRGPU_DIST_TIMING=1 in the environment: location 0 prints where a level's wall time went. */
+#define OCRGPU_RX_NO_CASCADE 1u
+int ocrgpu_resolve_exchange(ocrgpu_engine_t *e, uint32_t flags, uint64_t *levels_out);
+int ocrgpu_resolve_exchange_local(ocrgpu_engine_t **engines, uint32_t n, uint32_t flags, uint64_t *levels_out);
+
+/* ---- workpile (replaces ocrWorkpileFcts_t.push / pop, ocr/src/inc/ocr-workpile.h:39-84; hcWorkpilePush / hcWorkpilePop
+ *      ocr/src/workpile/hc/hc-workpile.c:103-150 on the deque of ocr/src/utils/deque.c:190-265): a deque of guids in HBM.
+ *      PUSH = at the tail, PUSHBACK = at the head (PUSH_WORKPUSHTYPE / PUSH_WORKPUSHBACKTYPE); POP = from the tail, newest first,
+ *      STEAL = from the head, oldest first (POP_WORKPOPTYPE / STEAL_WORKPOPTYPE).  *n_out = 0 when it is empty (the reference
+ *      returns NULL_GUID); a full workpile is OCRGPU_ENOMEM (the reference asserts, deque.c:194).  Capacity max_edt + 1024.
+ *      (EDTs the ENGINE makes ready are handed out by ocrgpu_pop_ready; this pair serves schedulers that keep their own
+ *      work-list of guids -- the LEGACY HC scheduler, hc-scheduler.c:207-334 -- and a heuristic that wants to re-queue.) ------ */
+enum { OCRGPU_WP_PUSH = 0, OCRGPU_WP_PUSHBACK = 1 };
+enum { OCRGPU_WP_POP = 0, OCRGPU_WP_STEAL = 1 };
+int ocrgpu_workpile_push(ocrgpu_engine_t *e, uint32_t type, uint64_t n, const uint64_t *guids, int where);
+int ocrgpu_workpile_pop(ocrgpu_engine_t *e, uint32_t type, uint64_t max_n, uint64_t *guids_out, uint64_t *n_out, int where);
+
 /* snapshot / restore of all mutable dependence state (benchmark loops re-arm a built DAG) */
 int ocrgpu_snapshot(ocrgpu_engine_t *e);
 int ocrgpu_restore(ocrgpu_engine_t *e);

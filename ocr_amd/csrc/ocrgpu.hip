@@ -23,6 +23,9 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
+#include <dlfcn.h>
+#include <time.h>
+#include <rccl/rccl.h>   // types only: the library is opened at ocrgpu_comm_init (dlopen), never linked
 #include "ocrgpu.h"
 #include "ocr_opstream.h"
 
@@ -557,6 +560,35 @@ __device__ __forceinline__ bool chan_satisfy(const Dev &d, u32 x, u32 payload, u
 // same latch are grouped (readfirstlane + ballot) and ONE atomic applies their summed +1/-1; the group
 // fires iff the counter it leaves is 0 (well-formed programs never pass through 0 before their last op).
 // A slot above 1 is OCRGPU_LATCH_DELTA(k): the net of several ops one caller made in a row (k may be 0).
+// In two halves, so that a caller can put other memory operations between the counter atomics and the look at what they
+// returned: latch_issue leaves, in the leader lane of each group, the old counter value and the group's delta.
+__device__ __forceinline__ void latch_issue(const Dev &d, bool is_latch, u32 x, u32 slot, bool &lead, s32 &old_out, s32 &delta_out) {
+    u64 todo = __ballot(is_latch);
+    const u64 general = __ballot(is_latch && slot > 1u);
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        u32 x0 = __shfl(x, leader);
+        u64 grp = __ballot(is_latch && x == x0) & todo;
+        u64 inc = __ballot(is_latch && x == x0 && slot == OCRLATCH_INCR) & todo;
+        u64 gen = grp & general;
+        s32 delta = (s32)__popcll(inc) - (s32)__popcll(grp & ~inc & ~gen);
+        while (gen) { // wave-uniform, rare
+            int b = __ffsll((long long)gen) - 1;
+            delta += (s32)(__shfl(slot, b) - OCRGPU_LATCH_DELTA_BIAS);
+            gen &= gen - 1;
+        }
+        if ((int)lane_id() == leader) { lead = true; delta_out = delta; old_out = atomicAdd(evt_val(d, x0), delta); } // no state read in front of it: one hop, not two
+        todo &= ~grp;
+    }
+}
+__device__ __forceinline__ bool latch_resolve(const Dev &d, bool lead, u32 x, s32 old, s32 delta) {
+    bool fire = false;
+    if (lead && old + delta == 0) {
+        u32 was = atomicExch(evt_state(d, x), ST_DESTROYED | (OCREVT_LATCH << 8));
+        if ((was & 0xFF) == ST_LIVE) fire = true; else atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
+    }
+    return fire;
+}
 __device__ __forceinline__ bool latch_group(const Dev &d, bool is_latch, u32 x, u32 slot) {
     bool fire = false;
     u64 todo = __ballot(is_latch);
@@ -650,13 +682,20 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
             const u64 w = d.waiters[seg[lo].row + (t - start)];
             u32 whi = (u32)(w >> 32);
             dst = (u32)w; flags = whi >> 28; slot = whi & 0x0FFFFFFFu; payload = seg[lo].payload;
-            if (flags & RF_DST_EDT) ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, dst, slot, payload, flags);
-            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote(d, rd.guid, rd.slot, rd.flags, payload); }
-            else {
+            if (!(flags & (RF_DST_EDT | RF_REMOTE))) {
                 to_evt = true;
                 if (flags & RF_DST_LATCH) { is_latch = true; kind = OCREVT_LATCH; }
                 else kind = (*evt_state(d, dst) >> 8) & 0xFF;
             }
+        }
+        // LATCH destinations first (hc-event.c:812-868): their counter atomics -- every leaf of a finish scope hits the same
+        // word, and same-address atomics queue up at ~10 ns each -- are in flight beside the pre-slot atomics below instead of
+        // behind the ready-log stores; what they returned is looked at in the event block at the end of the pass
+        bool l_lead = false; s32 l_old = 0, l_delta = 0;
+        if (__ballot(is_latch)) latch_issue(d, is_latch, dst, slot, l_lead, l_old, l_delta);
+        if (act) {
+            if (flags & RF_DST_EDT) ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, dst, slot, payload, flags);
+            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote(d, rd.guid, rd.slot, rd.flags, payload); }
         }
         // statistics are wave totals (one ballot each), so the epilogue needs no cross-lane reduction
         n_edt_sat += __popcll(__ballot(act && (flags & RF_DST_EDT))); n_evt_sat += __popcll(__ballot(to_evt));
@@ -665,7 +704,7 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         // event -> event dependences: run the destination's satisfy logic right here (commonSatisfyRegNode
         // recursing into processMessage, hc-event.c:335-367); only an event that FIRES costs a queue record
         if (__ballot(to_evt)) {
-            bool fire = latch_group(d, is_latch, dst, slot);
+            bool fire = latch_resolve(d, l_lead, dst, l_old, l_delta);
             u32 cw = 0; bool paired = false;
             if (to_evt && !is_latch) {
                 if (kind == OCREVT_ONCE || kind == OCREVT_STICKY || kind == OCREVT_IDEM || kind == OCREVT_COUNTED) fire = evt_satisfy_simple(d, dst, kind, payload);
@@ -1432,7 +1471,24 @@ __global__ void k_exchange_headers(Dev d, u32 K) {
     for (u32 l = 0; l < d.n_loc; ++l) { u32 c = d.send_cnt[l * 32]; sent += c > d.send_cap ? d.send_cap : c; }
     u32 mine = d.send_cnt[loc * 32]; if (mine > d.send_cap) mine = d.send_cap;
     u64 *h = (u64 *)&d.send[(size_t)loc * d.send_cap + (d.send_cap - 1)];
-    h[0] = mine; h[1] = (u64)(S->r_end - S->r_begin) + sent; h[2] = 0; h[3] = 0;
+    h[0] = mine; h[1] = (u64)(S->r_end - S->r_begin) + sent; h[2] = sent; h[3] = S->q_total > S->q_end ? S->q_total - S->q_end : 0;
+}
+// the receive side of the equal-split exchange, counts taken from the headers on the device (no host read in between):
+// region s of `recs` (stride records, header in the last slot) carries hdr[0] records from partition s
+__global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec *recs, u32 db_floor) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const u32 s = (u32)(i / (stride - 1)); const u64 k = i % (stride - 1);
+    if (s >= n_src) return;
+    const u64 cnt = recs[(u64)s * stride + (stride - 1)].guid; // header word 0
+    if (k < cnt) apply_record(d, recs[(u64)s * stride + k], db_floor);
+}
+// sums of the received headers: out[0] = records received, out[1] = activity of all partitions (ready-log entries fired +
+// records sent), out[2] = records sent by all, out[3] = satisfies still queued somewhere
+__global__ void k_exchange_sum_hdr(u32 n_src, u64 stride, const SendRec *recs, u64 *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u64 a = 0, b = 0, c = 0, q = 0;
+    for (u32 s = 0; s < n_src; ++s) { const u64 *h = (const u64 *)&recs[(u64)s * stride + (stride - 1)]; a += h[0]; b += h[1]; c += h[2]; q += h[3]; }
+    out[0] = a; out[1] = b; out[2] = c; out[3] = q;
 }
 __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
 __global__ void k_exchange_counts(Dev d, u32 *out) { if (threadIdx.x < d.n_loc) { u32 c = d.send_cnt[threadIdx.x * 32]; out[threadIdx.x] = c > d.send_cap ? d.send_cap : c; } }
@@ -1616,6 +1672,9 @@ struct ocrgpu_engine {
     u32 *pinned_done; u32 apply_flip; hipEvent_t apply_ev[2];
     DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB: the device tables (the device finds them through Ctrl)
     u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
+    // comm-platform over RCCL (ocrgpu_comm_*): communicator of this partition, receive regions, a small device word block
+    void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records; u64 *xsum_dev;
+    u64 *wp; u64 wp_cap, wp_head, wp_tail; // workpile: ring of guids in HBM, indices kept by the (single) caller side
 };
 
 static int dalloc(ocrgpu_engine *e, void **p, size_t bytes, bool zero = true) {
@@ -1714,6 +1773,8 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     { int sr = scratch_setup(device); if (sr) return sr; } // this GPU's address of the static scratch array (ocrgpu_pop_ready_noalloc)
     ocrgpu_engine *e = new ocrgpu_engine();
     e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
+    e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0; e->xsum_dev = nullptr;
+    e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->seal_epoch = 0; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->snap.dbl = nullptr; e->have_events = false;
@@ -1821,6 +1882,9 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
         }
 } }
 #endif
+    if (e->comm) (void)ocrgpu_comm_fini(e);
+    if (e->recv_buf) (void)hipFree(e->recv_buf);
+    if (e->xsum_dev) (void)hipFree(e->xsum_dev);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stage_dev) (void)hipFree(e->stage_dev);
     if (e->scan_partials) (void)hipFree(e->scan_partials);
@@ -2376,6 +2440,263 @@ extern "C" int ocrgpu_exchange_apply(ocrgpu_engine_t *e, const void *recs, u64 n
     k_exchange_apply<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dr, e->n_db);
     HIPCHK(hipGetLastError());
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// comm-platform over RCCL (takes the place of ocr/src/comm-platform/mpi/mpi-comm-platform.c: MPI_Init :54, the
+// MPI_Isend of one marshalled ocrPolicyMsg_t per remote PD_MSG_DEP_SATISFY :1055, MPI_Iprobe/Irecv :287,620-642, behind
+// ocrCommPlatformFcts_t ocr/src/inc/ocr-comm-platform.h:55-199).  One communicator rank per engine = per GPU = per
+// policy-domain location.  What crosses xGMI per level is ONE equal-split all-to-all of the engine's send regions (32-byte
+// records, header in the last slot of each region), as grouped ncclSend / ncclRecv on the engine's stream; the counts the
+// receiver needs ride in the headers, so nothing comes back to the host between the step that filled the regions and the
+// kernel that applies what arrived.  librccl is opened with dlopen when the first communicator is made: a single-GPU user
+// of libocrgpu needs no RCCL at all, and a process that already holds torch's copy of the library shares it.
+// ------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void *lib;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*GroupStart)();
+    ncclResult_t (*GroupEnd)();
+    const char *(*GetErrorString)(ncclResult_t);
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+    if (g_rccl.lib) return 0;
+    const char *names[] = {getenv("OCRGPU_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) { if (n && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break; }
+    if (!h) FAIL(OCRGPU_ENOTSUP, "librccl not found (dlopen: %s)", dlerror());
+    RcclApi a; a.lib = h;
+#define SYM(field, name) do { *(void **)&a.field = dlsym(h, name); if (!a.field) FAIL(OCRGPU_ENOTSUP, "librccl lacks %s", name); } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl = a;
+    return 0;
+}
+#define RCCLCHK(call) do { ncclResult_t _r = (call); if (_r != ncclSuccess) { snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString(_r)); return OCRGPU_EHIP; } } while (0)
+
+extern "C" int ocrgpu_comm_get_unique_id(void *id128_out) {
+    if (!id128_out) FAIL(OCRGPU_EINVAL, "null argument");
+    int r = rccl_load(); if (r) return r;
+    ncclUniqueId id;
+    RCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(id128_out, &id, sizeof id);
+    return 0;
+}
+static int exchange_buffers(ocrgpu_engine *e) { // receive regions + the header sums, sized by the configured send regions
+    Dev &d = e->d;
+    if (!d.send_cnt || !d.send || d.send_cap < 2) FAIL(OCRGPU_EINVAL, "exchange not configured (ocrgpu_exchange_config first)");
+    const u64 need = (u64)d.n_loc * d.send_cap;
+    if (!e->recv_buf || e->recv_cap_records < need) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->recv_buf) (void)hipFree(e->recv_buf);
+        HIPCHK(hipMalloc((void **)&e->recv_buf, sizeof(SendRec) * need));
+        e->recv_cap_records = need;
+    }
+    if (!e->xsum_dev) HIPCHK(hipMalloc((void **)&e->xsum_dev, 64));
+    return 0;
+}
+extern "C" int ocrgpu_comm_init(ocrgpu_engine_t *e, const void *id128, int rank, int nranks) {
+    ENTER(e);
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) FAIL(OCRGPU_EINVAL, "bad rank %d of %d", rank, nranks);
+    if (e->comm) FAIL(OCRGPU_EINVAL, "this engine already has a communicator");
+    if ((u32)nranks != e->d.n_loc || (u32)rank != e->cfg.location) FAIL(OCRGPU_EINVAL, "rank %d of %d does not match location %u of %u (ocrgpu_exchange_config)", rank, nranks, e->cfg.location, e->d.n_loc);
+    int r = rccl_load(); if (r) return r;
+    if ((r = exchange_buffers(e))) return r;
+    ncclUniqueId id; memcpy(&id, id128, sizeof id);
+    ncclComm_t c = nullptr;
+    RCCLCHK(g_rccl.CommInitRank(&c, nranks, id, rank));
+    e->comm = (void *)c; e->comm_rank = rank; e->comm_nranks = nranks;
+    return 0;
+}
+extern "C" int ocrgpu_comm_fini(ocrgpu_engine_t *e) {
+    if (!e) FAIL(OCRGPU_EINVAL, "null engine");
+    if (!e->comm) return 0;
+    (void)hipSetDevice(e->device); (void)hipStreamSynchronize(e->stream);
+    ncclResult_t r = g_rccl.CommDestroy((ncclComm_t)e->comm);
+    e->comm = nullptr;
+    if (r != ncclSuccess) FAIL(OCRGPU_EHIP, "ncclCommDestroy -> %s", g_rccl.GetErrorString(r));
+    return 0;
+}
+// the transport itself: region p of send_dev goes to rank p, region p of recv_dev comes from rank p (bytes_per_peer each)
+extern "C" int ocrgpu_comm_alltoall(ocrgpu_engine_t *e, const void *send_dev, void *recv_dev, u64 bytes_per_peer) {
+    ENTER(e);
+    if (!e->comm) FAIL(OCRGPU_EINVAL, "no communicator (ocrgpu_comm_init)");
+    if (!send_dev || !recv_dev) FAIL(OCRGPU_EINVAL, "null buffer");
+    if (bytes_per_peer == 0) return 0;
+    ncclComm_t c = (ncclComm_t)e->comm;
+    RCCLCHK(g_rccl.GroupStart());
+    for (int p = 0; p < e->comm_nranks; ++p) {
+        ncclResult_t a = g_rccl.Send((const char *)send_dev + (size_t)p * bytes_per_peer, bytes_per_peer, ncclUint8, p, c, e->stream);
+        ncclResult_t b = a == ncclSuccess ? g_rccl.Recv((char *)recv_dev + (size_t)p * bytes_per_peer, bytes_per_peer, ncclUint8, p, c, e->stream) : a;
+        if (b != ncclSuccess) { (void)g_rccl.GroupEnd(); FAIL(OCRGPU_EHIP, "ncclSend/ncclRecv with rank %d -> %s", p, g_rccl.GetErrorString(b)); }
+    }
+    RCCLCHK(g_rccl.GroupEnd());
+    return 0;
+}
+// One exchange round, in three stages so that the same protocol runs over RCCL (one engine per process) and over plain
+// device-to-device copies (several partitions in one process: the tests).  xchg_post: headers into the send regions.
+// xchg_land: apply what arrived, clear the send counters, bring back the header sums (the round's ONE synchronisation).
+static int xchg_post(ocrgpu_engine *e) {
+    int r = exchange_buffers(e); if (r) return r;
+    if (e->d.n_loc > 1024) FAIL(OCRGPU_EINVAL, "more than 1024 locations");
+    k_exchange_headers<<<1, 1024, 0, e->stream>>>(e->d, e->launch_index);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int xchg_land(ocrgpu_engine *e, u64 *out4) {
+    Dev &d = e->d;
+    const u64 n = (u64)d.n_loc * (d.send_cap - 1);
+    k_exchange_apply_hdr<<<nblk(n), 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, e->recv_buf, e->n_db);
+    k_exchange_reset<<<1, 1024, 0, e->stream>>>(d);
+    k_exchange_sum_hdr<<<1, 1, 0, e->stream>>>(d.n_loc, d.send_cap, e->recv_buf, e->xsum_dev);
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33040, e->xsum_dev, 32, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    memcpy(out4, e->pinned_done + 33040, 32);
+    return 0;
+}
+extern "C" int ocrgpu_exchange(ocrgpu_engine_t *e, u64 *records_in_out, u64 *activity_out, u64 *sent_out, u64 *queued_out) {
+    ENTER(e);
+    if (!e->comm) FAIL(OCRGPU_EINVAL, "no communicator (ocrgpu_comm_init)");
+    int r = xchg_post(e); if (r) return r;
+    if ((r = ocrgpu_comm_alltoall(e, e->d.send, e->recv_buf, sizeof(SendRec) * (u64)e->d.send_cap))) return r;
+    u64 h[4];
+    if ((r = xchg_land(e, h))) return r;
+    if (records_in_out) *records_in_out = h[0];
+    if (activity_out) *activity_out = h[1];
+    if (sent_out) *sent_out = h[2];
+    if (queued_out) *queued_out = h[3];
+    return 0;
+}
+extern "C" int ocrgpu_exchange_local(ocrgpu_engine_t **engines, u32 n, u64 *activity_out, u64 *sent_out, u64 *queued_out) {
+    if (!engines || n == 0) FAIL(OCRGPU_EINVAL, "no engines");
+    for (u32 i = 0; i < n; ++i) {
+        if (!engines[i] || engines[i]->d.n_loc != n || engines[i]->cfg.location != i || engines[i]->d.send_cap != engines[0]->d.send_cap ||
+            engines[i]->device != engines[0]->device) FAIL(OCRGPU_EINVAL, "engine %u: the group must be locations 0..n-1 of one n-way partition on one device, equal regions", i);
+        HIPCHK(hipSetDevice(engines[i]->device));
+        int r = xchg_post(engines[i]); if (r) return r;
+    }
+    for (u32 i = 0; i < n; ++i) HIPCHK(hipStreamSynchronize(engines[i]->stream)); // the copies below read every engine's regions
+    const size_t reg = sizeof(SendRec) * (size_t)engines[0]->d.send_cap;
+    for (u32 src = 0; src < n; ++src)
+        for (u32 dst = 0; dst < n; ++dst)
+            HIPCHK(hipMemcpyAsync((char *)engines[dst]->recv_buf + (size_t)src * reg, (const char *)engines[src]->d.send + (size_t)dst * reg, reg,
+                                  hipMemcpyDeviceToDevice, engines[dst]->stream));
+    for (u32 i = 0; i < n; ++i) HIPCHK(hipStreamSynchronize(engines[i]->stream)); // (the engines may sit on different streams)
+    u64 h[4] = {0, 0, 0, 0};
+    for (u32 i = 0; i < n; ++i) { int r = xchg_land(engines[i], h); if (r) return r; }
+    if (activity_out) *activity_out = h[1];
+    if (sent_out) *sent_out = h[2];
+    if (queued_out) *queued_out = h[3];
+    return 0;
+}
+// The distributed worker loop (hc-dist's role for this path, hc-dist-policy.c:1027-1031,2208): every partition fires one level,
+// exchanges, and applies; a level is closed (no record in flight, no satisfy queued anywhere) before the next one fires, so
+// level numbers are those of the single-partition run.  OCRGPU_RX_NO_CASCADE: the caller vouches that a satisfy arriving from
+// another partition never sends one on (no event -> remote waiter chains): one exchange per level is then enough.
+// One group = the engines of this process (1 with RCCL; several in the lockstep tests).
+static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+static int group_round(ocrgpu_engine **g, u32 n, bool rccl, u32 fire, u32 step_flags, u64 *h, double *tm) {
+    const double t0 = now_s();
+    for (u32 i = 0; i < n; ++i) { int r = ocrgpu_step(g[i], fire, step_flags, nullptr, nullptr, nullptr); if (r && r != OCRGPU_EFAULT) return r; }
+    const double t1 = now_s();
+    u64 rin = 0;
+    int r = rccl ? ocrgpu_exchange(g[0], &rin, &h[1], &h[2], &h[3]) : ocrgpu_exchange_local(g, n, &h[1], &h[2], &h[3]);
+    if (tm) { tm[0] += t1 - t0; tm[1] += now_s() - t1; }
+    return r;
+}
+static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags, u64 *levels_out) {
+    u64 h[4] = {0, 0, 0, 0}, levels = 0;
+    double tm[2] = {0, 0}; const bool timing = getenv("OCRGPU_DIST_TIMING") != nullptr;
+    int r;
+    do { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, nullptr))) return r; } while (h[2] || h[3]); // what the main program sent settles first
+    for (;;) {
+        if ((r = group_round(g, n, rccl, 1u, OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr))) return r;
+        const u64 act = h[1];
+        if (!(flags & OCRGPU_RX_NO_CASCADE) || h[3])
+            while (h[2] || h[3]) { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr))) return r; }
+        if (act == 0) break; // nobody fired or sent anything: the probe level is dropped below
+        ++levels;
+    }
+    for (u32 i = 0; i < n; ++i) { r = ocrgpu_step(g[i], 0u, OCRGPU_STEP_DROP_EMPTY_LEVEL, nullptr, nullptr, nullptr); if (r && r != OCRGPU_EFAULT) return r; }
+    if (timing && g[0]->cfg.location == 0 && levels)
+        fprintf(stderr, "[ocrgpu dist timing] us per level: engine step %.1f | exchange (headers, all-to-all, apply, one sync) %.1f | %llu levels\n",
+                1e6 * tm[0] / (double)(levels + 1), 1e6 * tm[1] / (double)(levels + 1), (unsigned long long)levels);
+    if (levels_out) *levels_out = levels;
+    return 0;
+}
+extern "C" int ocrgpu_resolve_exchange(ocrgpu_engine_t *e, u32 flags, u64 *levels_out) {
+    if (!e) FAIL(OCRGPU_EINVAL, "null engine");
+    if (!e->comm) FAIL(OCRGPU_EINVAL, "no communicator (ocrgpu_comm_init)");
+    return resolve_exchange_group(&e, 1, true, flags, levels_out);
+}
+extern "C" int ocrgpu_resolve_exchange_local(ocrgpu_engine_t **engines, u32 n, u32 flags, u64 *levels_out) {
+    if (!engines || n == 0) FAIL(OCRGPU_EINVAL, "no engines");
+    return resolve_exchange_group(engines, n, false, flags, levels_out);
+}
+
+// ---- workpile (ocrWorkpileFcts_t.push / pop, ocr/src/inc/ocr-workpile.h:39-84; hcWorkpilePush / hcWorkpilePop
+//      ocr/src/workpile/hc/hc-workpile.c:103-150 over deque.c:190-265): a deque of guids kept in HBM.  PUSH appends at the tail,
+//      PUSHBACK at the head; POP takes from the tail (the owner's LIFO end), STEAL from the head (FIFO).  One caller at a time per
+//      engine, like every other entry point, so the two indices live on the caller's side and the ring holds only the guids. ----
+extern "C" int ocrgpu_workpile_push(ocrgpu_engine_t *e, u32 type, u64 n, const u64 *guids, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!guids || type > OCRGPU_WP_PUSHBACK) FAIL(OCRGPU_EINVAL, "bad argument");
+    if (!e->wp) {
+        e->wp_cap = (u64)e->cfg.max_edt + 1024; // INIT_DEQUE_CAPACITY's role (ocr/src/inc/utils/deque.h:15-18): every EDT can be in it once
+        HIPCHK(hipMalloc((void **)&e->wp, 8 * e->wp_cap));
+        e->allocs.push_back(e->wp);
+        e->wp_head = e->wp_tail = e->wp_cap; // start in the middle of the index space: PUSHBACK moves the head down
+    }
+    if (e->wp_tail - e->wp_head + n > e->wp_cap) FAIL(OCRGPU_ENOMEM, "workpile full (%llu entries; the reference's deque asserts here, deque.c:194)", (unsigned long long)e->wp_cap);
+    const hipMemcpyKind kind = where == OCRGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    u64 first = type == OCRGPU_WP_PUSH ? e->wp_tail : e->wp_head - n; // PUSHBACK of n guids: guids[0] ends up at the head
+    for (u64 done = 0; done < n;) {
+        const u64 pos = (first + done) % e->wp_cap, run = n - done < e->wp_cap - pos ? n - done : e->wp_cap - pos;
+        HIPCHK(hipMemcpyAsync(e->wp + pos, guids + done, 8 * run, kind, e->stream));
+        done += run;
+    }
+    if (type == OCRGPU_WP_PUSH) e->wp_tail += n; else e->wp_head -= n;
+    if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+extern "C" int ocrgpu_workpile_pop(ocrgpu_engine_t *e, u32 type, u64 max_n, u64 *guids_out, u64 *n_out, int where) {
+    ENTER(e);
+    if (!n_out || (max_n && !guids_out) || type > OCRGPU_WP_STEAL) FAIL(OCRGPU_EINVAL, "bad argument");
+    const u64 have = e->wp ? e->wp_tail - e->wp_head : 0, n = have < max_n ? have : max_n;
+    *n_out = n; // 0 = empty: the reference's pop returns NULL_GUID then
+    if (n == 0) return 0;
+    const hipMemcpyKind kind = where == OCRGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (type == OCRGPU_WP_STEAL) { // from the head, oldest first
+        for (u64 done = 0; done < n;) {
+            const u64 pos = (e->wp_head + done) % e->wp_cap, run = n - done < e->wp_cap - pos ? n - done : e->wp_cap - pos;
+            HIPCHK(hipMemcpyAsync(guids_out + done, e->wp + pos, 8 * run, kind, e->stream));
+            done += run;
+        }
+        e->wp_head += n;
+        HIPCHK(hipStreamSynchronize(e->stream));
+    } else { // from the tail, newest first: the run [tail-n, tail) is copied out and reversed on the way
+        if (where == OCRGPU_DEVICE) FAIL(OCRGPU_ENOTSUP, "OCRGPU_WP_POP fills host arrays only");
+        const u64 first = e->wp_tail - n;
+        for (u64 done = 0; done < n;) {
+            const u64 pos = (first + done) % e->wp_cap, run = n - done < e->wp_cap - pos ? n - done : e->wp_cap - pos;
+            HIPCHK(hipMemcpyAsync(guids_out + done, e->wp + pos, 8 * run, kind, e->stream));
+            done += run;
+        }
+        HIPCHK(hipStreamSynchronize(e->stream));
+        std::reverse(guids_out, guids_out + n);
+        e->wp_tail -= n;
+    }
     return 0;
 }
 

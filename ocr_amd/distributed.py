@@ -319,6 +319,13 @@ def resolve_lockstep(parts):
     return levels
 
 
+def resolve_lockstep_c(parts, no_cascade=False):
+    """The same, with the per-level loop and the exchange in C (ocrgpu_resolve_exchange_local: the protocol RCCL ranks run,
+    device-to-device copies standing in for the all-to-all)."""
+    from .engine import resolve_exchange_local
+    return resolve_exchange_local([p.eng for p in parts], no_cascade=no_cascade)
+
+
 HOST_GROUP = None   # set to a gloo group to route every collective of the exchange through host memory
 DEV_GROUP = None    # set to an RCCL ("nccl") group to keep the exchange on the GPUs when the default group is a gloo one
 

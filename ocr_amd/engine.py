@@ -66,7 +66,12 @@ EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error
            "ocrgpu_set_hash_tag_base", "ocrgpu_add_dependence", "ocrgpu_event_satisfy_slot", "ocrgpu_event_destroy", "ocrgpu_edt_release_dbs",
            "ocrgpu_resolve", "ocrgpu_step", "ocrgpu_step_info", "ocrgpu_pop_ready", "ocrgpu_pop_ready_noalloc", "ocrgpu_exchange_apply_strided", "ocrgpu_exchange_config", "ocrgpu_exchange_counts",
            "ocrgpu_exchange_reset", "ocrgpu_exchange_apply", "ocrgpu_snapshot", "ocrgpu_restore", "ocrgpu_sync", "ocrgpu_read_edts",
-           "ocrgpu_read_events", "ocrgpu_read_dbs", "ocrgpu_read_fired", "ocrgpu_get_stats"]
+           "ocrgpu_read_events", "ocrgpu_read_dbs", "ocrgpu_read_fired", "ocrgpu_get_stats",
+           "ocrgpu_comm_get_unique_id", "ocrgpu_comm_init", "ocrgpu_comm_fini", "ocrgpu_comm_alltoall", "ocrgpu_exchange",
+           "ocrgpu_exchange_local", "ocrgpu_resolve_exchange", "ocrgpu_resolve_exchange_local", "ocrgpu_workpile_push",
+           "ocrgpu_workpile_pop"]
+RX_NO_CASCADE = 1
+WP_PUSH, WP_PUSHBACK, WP_POP, WP_STEAL = 0, 1, 0, 1
 
 _lib = None
 
@@ -303,6 +308,41 @@ class Engine:
         self._chk(self.lib.ocrgpu_exchange_apply_strided(self.h, C.c_void_p(dev_ptr), C.c_uint32(n_src),
                                                          C.c_uint64(stride_records), _ptr(counts)))
 
+    # ---- the comm-platform over RCCL (C transport) ----
+    def comm_init(self, unique_id: bytes, rank, nranks):
+        """ncclCommInitRank for this engine (collective; exchange_config comes first)."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self.lib.ocrgpu_comm_init(self.h, buf, C.c_int(rank), C.c_int(nranks)))
+
+    def comm_fini(self):
+        self._chk(self.lib.ocrgpu_comm_fini(self.h))
+
+    def comm_alltoall(self, send_dev_ptr, recv_dev_ptr, bytes_per_peer):
+        self._chk(self.lib.ocrgpu_comm_alltoall(self.h, C.c_void_p(send_dev_ptr), C.c_void_p(recv_dev_ptr), C.c_uint64(bytes_per_peer)))
+
+    def exchange(self):
+        """One exchange round over RCCL: (records received here, activity of all, records sent by all, satisfies queued)."""
+        out = [C.c_uint64() for _ in range(4)]
+        self._chk(self.lib.ocrgpu_exchange(self.h, *[C.byref(x) for x in out]))
+        return tuple(int(x.value) for x in out)
+
+    def resolve_exchange(self, no_cascade=False):
+        """The worker loop across partitions, in C over RCCL (collective).  Returns the number of levels fired."""
+        lv = C.c_uint64()
+        self._chk(self.lib.ocrgpu_resolve_exchange(self.h, C.c_uint32(RX_NO_CASCADE if no_cascade else 0), C.byref(lv)))
+        return int(lv.value)
+
+    # ---- workpile (ocrWorkpileFcts_t push / pop) ----
+    def workpile_push(self, guids, back=False):
+        guids = np.ascontiguousarray(guids, np.uint64)
+        self._chk(self.lib.ocrgpu_workpile_push(self.h, C.c_uint32(WP_PUSHBACK if back else WP_PUSH), C.c_uint64(len(guids)), _ptr(guids), HOST))
+
+    def workpile_pop(self, max_n, steal=False):
+        out = np.empty(max_n, np.uint64)
+        n = C.c_uint64()
+        self._chk(self.lib.ocrgpu_workpile_pop(self.h, C.c_uint32(WP_STEAL if steal else WP_POP), C.c_uint64(max_n), _ptr(out), C.byref(n), HOST))
+        return out[:n.value]
+
     def snapshot(self):
         self._chk(self.lib.ocrgpu_snapshot(self.h))
 
@@ -340,6 +380,37 @@ class Engine:
         ls = np.zeros(nl.value + 1, np.uint64)
         self._chk(self.lib.ocrgpu_read_fired(self.h, C.byref(nf), C.byref(nl), _ptr(ids), _ptr(ls), HOST))
         return ids, ls
+
+
+def comm_get_unique_id() -> bytes:
+    """ncclGetUniqueId through libocrgpu (rank 0 calls it and hands the 128 bytes to the other ranks)."""
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.ocrgpu_comm_get_unique_id(buf)
+    if rc != 0:
+        raise OcrGpuError(rc, (lib.ocrgpu_last_error() or b"").decode())
+    return buf.raw
+
+
+def _engine_array(engines):
+    arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    return arr
+
+
+def exchange_local(engines):
+    """One exchange round among the partitions of this process (locations 0..n-1 on one GPU): (activity, sent, queued)."""
+    lib = engines[0].lib
+    out = [C.c_uint64() for _ in range(3)]
+    engines[0]._chk(lib.ocrgpu_exchange_local(_engine_array(engines), C.c_uint32(len(engines)), *[C.byref(x) for x in out]))
+    return tuple(int(x.value) for x in out)
+
+
+def resolve_exchange_local(engines, no_cascade=False):
+    lib = engines[0].lib
+    lv = C.c_uint64()
+    engines[0]._chk(lib.ocrgpu_resolve_exchange_local(_engine_array(engines), C.c_uint32(len(engines)),
+                                                       C.c_uint32(RX_NO_CASCADE if no_cascade else 0), C.byref(lv)))
+    return int(lv.value)
 
 
 class StreamProgram:

@@ -42,7 +42,7 @@ def test_bench_two_ranks_on_one_gpu(backend, launcher):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["config"]["n_edt"] == 2 * 400000 + 1 and 100 <= out["config"]["levels"] <= 103   # 100 layers + latch/sink
     wl = out["config"]["workload"]
-    assert "all-to-all (gloo" in wl or "all-to-all (nccl" in wl   # one GPU: gloo (RCCL refuses two ranks on one device); more: RCCL may come up
+    assert "all-to-all (gloo" in wl or "all-to-all (RCCL" in wl   # one GPU: gloo (RCCL refuses two ranks on one device); more: RCCL may come up
     if backend == "gloo":
         assert "all-to-all (gloo" in wl
     assert out["roofline"]["frac"] > 0
