@@ -236,7 +236,8 @@ int ocrgpu_pop_ready_noalloc(ocrgpu_engine_t *e, uint64_t max_edts, uint64_t max
  *      per-destination send buffers with 32-byte records; the caller moves them (RCCL all-to-all over xGMI) and
  *      hands what it received to ocrgpu_exchange_apply.                                                 ---------- */
 typedef struct { uint64_t guid; uint32_t slot, flags; uint64_t value, tag; } ocrgpu_sendrec_t;   /* 32 B */
-/* send_dev_buf: caller-owned DEVICE buffer of n_locations * records_per_dest records (region r = destination r).
+/* send_dev_buf: caller-owned DEVICE buffer of n_locations * records_per_dest records (region r = destination r), or NULL:
+ * the engine allocates the regions itself (freed by ocrgpu_fini).
  * After this call API batches no longer drain by themselves: drive the engine with ocrgpu_step.               */
 int ocrgpu_exchange_config(ocrgpu_engine_t *e, uint32_t n_locations, void *send_dev_buf, uint64_t records_per_dest,
                            uint64_t max_remote_dsts);

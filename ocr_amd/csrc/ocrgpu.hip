@@ -2373,8 +2373,11 @@ extern "C" int ocrgpu_exchange_config(ocrgpu_engine_t *e, u32 n_locations, void 
     ENTER(e);
     if (e->dbl) FAIL(OCRGPU_EINVAL, "OCRGPU_F_LOCKABLE_DB arbitrates within one partition: not with an exchange configured");
     if (n_locations == 0 || n_locations > 1024 || e->cfg.location >= n_locations) FAIL(OCRGPU_EINVAL, "bad n_locations");
-    if (n_locations > 1 && (!send_dev_buf || records_per_dest == 0 || records_per_dest > 0xFFFFFFFFull)) FAIL(OCRGPU_EINVAL, "send buffer required");
+    if (n_locations > 1 && (records_per_dest == 0 || records_per_dest > 0xFFFFFFFFull)) FAIL(OCRGPU_EINVAL, "records_per_dest must be in [1, 2^32)");
     Dev &d = e->d;
+    if (!send_dev_buf && records_per_dest) { // the engine owns the send regions (a plain C host has no device allocator)
+        int r = dalloc(e, &send_dev_buf, sizeof(SendRec) * (size_t)n_locations * (size_t)records_per_dest); if (r) return r;
+    }
     d.n_loc = n_locations; d.send = (SendRec *)send_dev_buf; d.send_cap = (u32)records_per_dest;
     if (!e->send_cnt_dev) { int r = dalloc(e, (void **)&e->send_cnt_dev, 4 * 32 * 1024); if (r) return r; }
     d.send_cnt = e->send_cnt_dev;
