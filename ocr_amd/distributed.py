@@ -39,6 +39,23 @@ def default_owner(idx, world):
         return ((idx * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)) % np.uint64(world)
 
 
+def stencil_block_owner(G, steps, world, grid=None):
+    """Block partition of BASELINE config 4 (the reference places an object by the LOCHOME bits its creator
+    chose, ocr/src/guid/guid-bitmap-based.c:25-58; a stencil program chooses them by tile position): tile (i, j) of every
+    time step lives on block (i // bh, j // bw) of a py x px grid of ranks (2 x 4 for 8 GPUs), so only the halo edges along block
+    borders cross partitions.  Returns owner_edt for :class:`Partition` (the sink EDT goes to rank 0)."""
+    if grid is None:
+        py = 1
+        while (2 * py) ** 2 <= world and world % (2 * py) == 0:   # the squarest py x px with py <= px: 2 x 4 for 8, 2 x 2 for 4
+            py *= 2
+        grid = (py, world // py)
+    py, px = grid
+    assert py * px == world and G % py == 0 and G % px == 0, (grid, G)
+    ii, jj = np.divmod(np.arange(G * G, dtype=np.int64), G)
+    tile_owner = (ii // (G // py)) * px + jj // (G // px)
+    return np.r_[np.tile(tile_owner, steps), 0].astype(np.int64)
+
+
 class Partition:
     """One rank's share of an op stream.  Every rank walks the same main-op list and executes the ops whose
     executor it is: creations by the owner, ocrAddDependence by the owner of the source (the waiter list lives
@@ -46,11 +63,14 @@ class Partition:
     payload DB (else of the event).  GUIDs of remote objects are predicted: every engine hands out counters in
     creation order, so all ranks can compute all GUIDs from the stream alone (checked against the real ones)."""
 
-    def __init__(self, s: OpStream, rank: int, world: int, device=0, flags=0, send_cap=None, torch=None):
+    def __init__(self, s: OpStream, rank: int, world: int, device=0, flags=0, send_cap=None, torch=None, owner_edt=None):
+        """owner_edt: rank of every EDT (array of s.n_edt) in place of the hash partition -- the placement hook: an EDT's
+        output event and output datablock live with it, so this decides which dependences cross partitions."""
         import torch as _torch
         self.torch = torch or _torch
         self.s, self.rank, self.world = s, rank, world
-        self.own_edt = default_owner(np.arange(s.n_edt), world).astype(np.int64)
+        self.own_edt = (default_owner(np.arange(s.n_edt), world) if owner_edt is None else np.asarray(owner_edt)).astype(np.int64)
+        assert len(self.own_edt) == s.n_edt and self.own_edt.min() >= 0 and self.own_edt.max() < world
         self.own_evt = default_owner(np.arange(s.n_evt) + (1 << 40), world).astype(np.int64)
         self.own_db = default_owner(np.arange(s.n_db) + (2 << 40), world).astype(np.int64)
         self._predict_guids()
@@ -307,14 +327,18 @@ def build_lockstep(parts):
         _lockstep_settle(parts)
 
 
-def resolve_lockstep(parts):
+def resolve_lockstep(parts, count_records=None):
     """Drive several partitions that live in ONE process (tests: all on one GPU).  Same protocol as
-    :func:`resolve_distributed`."""
+    :func:`resolve_distributed`.  ``count_records``: a list that receives the number of records each firing round put on the
+    wire (the level's own fan-out; records that cascade in the settle rounds behind it are not counted)."""
     W = len(parts)
     levels = 0
     M = _lockstep_settle(parts)
     while M[:, W].sum() > 0:
-        M = _lockstep_settle(parts, _lockstep_round(parts, True))
+        M = _lockstep_round(parts, True)
+        if count_records is not None:
+            count_records.append(int(M[:, :W].sum()))
+        M = _lockstep_settle(parts, M)
         levels += 1
     return levels
 
