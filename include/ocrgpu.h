@@ -177,6 +177,35 @@ int ocrgpu_event_satisfy_slot(ocrgpu_engine_t *e, uint64_t n, const uint64_t *ev
                               const uint32_t *slot, int where);
 /* ocrEventDestroy (ocr-edt.c:101) */
 int ocrgpu_event_destroy(ocrgpu_engine_t *e, uint64_t n, const uint64_t *evt, int where);
+
+/* ---- capacity is what is alive, not what was ever created ------------------------------------------------------
+ * The reference frees an EDT when its body has returned (destructTaskHc, hc-task.c:721-790), an event when it is destroyed
+ * (destructEventHc, hc-event.c:185-242: ONCE/LATCH/COUNTED events by their own satisfy) and a datablock on ocrDbDestroy
+ * (regular-datablock.c:388-470), each time releasing the guid (counted-map-guid.c:540-572 -> hashtable.c:556-575).  Here
+ * objects are rows of fixed-size tables, so the same moments put the row on a free stack that the create calls serve
+ * first; the guid leaves the table, and its slot there is reused by later puts.                                          */
+/* ocrDbDestroy: the guids stop resolving; explicit datablocks give their index back at once, the output datablock of a HASH
+ * EDT marks its EDT's line as free to go.  A datablock some EDT is still to read must not be destroyed (as in the
+ * reference: use after free).  Unknown guid / not a datablock: err[4], OCRGPU_EFAULT.                                   */
+int ocrgpu_db_destroy(ocrgpu_engine_t *e, uint64_t n, const uint64_t *guids, int where);
+typedef struct {
+    uint64_t edts_freed, events_freed;  /* rows taken back by this call                                                  */
+    uint64_t edts_held;                 /* EDTs that fired but cannot go yet: output event not fired, output datablock of
+                                           a HASH body not destroyed, or a frontier table still in use                   */
+    uint64_t edges_kept;                /* registrations still waiting on a live event; max_edges - edges_kept are free  */
+    uint64_t free_edt, free_evt, free_db;    /* heights of the free stacks after the call                                */
+    uint64_t fresh_edt, fresh_evt, fresh_db; /* rows never used so far: a create of n objects succeeds iff n <= free + fresh */
+    uint64_t slots_used;                /* overflow pre-slot words in use (start over once no EDT with depc > 6 is left)  */
+    uint64_t ready_kept;                /* entries the ready log starts over with                                         */
+} ocrgpu_reclaim_t;
+/* Take back the rows of every EDT that has fired and is done, and of every destroyed event; drop the registrations of
+ * events that have fired; start the ready log and the level numbering over (ocrgpu_read_edts / ocrgpu_read_fired results
+ * from before the call are gone, and so is the snapshot).  "Done": built-in bodies have run; for OCRBODY_HOST the caller
+ * promises that every EDT ocrgpu_pop_ready has handed out so far has returned (EDTs that fired but were not handed out
+ * yet stay in the ready log).  An EDT with OCRBODY_F_OUTEVT goes once that event has fired, one with a HASH body once its
+ * output datablock was destroyed.  Call between ocrgpu_step / ocrgpu_resolve calls; pending satisfy records are applied
+ * first.  Not reclaimed: CHANNEL rings of destroyed CHANNEL events, remote-destination records (max_remote_dsts).      */
+int ocrgpu_reclaim(ocrgpu_engine_t *e, ocrgpu_reclaim_t *out);
 /* OCRGPU_F_LOCKABLE_DB with host-run bodies (OCRBODY_HOST): the EDTs named have run -- release every datablock they
  * acquired (taskEpilogue's release loop, hc-task.c:1723-1751 -> lockableRelease lockable-datablock.c:330); EDTs the
  * datablocks are handed to become ready in the next ocrgpu_step / ocrgpu_resolve.  Built-in bodies release by themselves. */

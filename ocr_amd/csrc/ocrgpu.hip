@@ -168,6 +168,16 @@ struct Dev {
     u32 spread_wgs;             // k_step: a short work list is dealt out over this many workgroups
 };
 
+// Reclaiming capacity (ocrgpu_reclaim / ocrgpu_db_destroy): the guids an EDT line / event record was created under (what the
+// reference's destructTaskHc hc-task.c:721 and destructEventHc hc-event.c:185-242 hand to PD_MSG_GUID_DESTROY), stacks of free
+// indices, and the EDTs that have fired but cannot be taken back yet.  Passed to the few kernels that need them as an argument
+// of their own: k_step's argument block stays as it was.
+struct EdtGuids { u64 edt, oevt, odb, pad; };
+struct ReclDev { EdtGuids *edt_guids; u64 *evt_guids; u32 *free_edt, *free_evt, *free_db, *held, *held_new, *cnt; };
+enum { RC_EDT = 0, RC_EVT, RC_DB, RC_HELD, RC_OVF_LIVE, RC_LAZY_LIVE, RC_LOG_KEPT, RC_LAZY_FREED, RC_UNPOPPED, RC_SCRIPT_LIVE, RC_READY, RC_N = 16 };
+#define BODY_DB_DEAD 0x80000000u // EdtLine.body: the output datablock of this (HASH) EDT has been destroyed (ocrgpu_db_destroy)
+#define BODY_FREE 0x40000000u    // EdtLine.body: the line is on the free stack
+
 #define TOMB (~0ULL)
 #define GRESV (~0ULL - 1)   // slot claimed, value not yet published (== UNINITIALIZED_GUID, never a key)
 
@@ -244,18 +254,20 @@ __device__ u64 gtab_get(const Dev &d, u64 key) {
 // shrink back and tryput (which only claims empty slots) keeps finding room in a table that has seen many removes.  Removes
 // run in batches of their own (no put or get in the same launch): within such a launch "the next slot is empty" stays true
 // once seen, which is what makes emptying a slot safe (no live key's probe path runs over it).
-__device__ void gtab_remove(const Dev &d, u64 key) {
+__device__ bool gtab_remove(const Dev &d, u64 key) { // true: this call took the key out (two removes of one key: one of them)
     u64 h = ghash(d, key);
     for (u64 probe = 0; probe <= d.gmask; ++probe, h = (h + 1) & d.gmask) {
         const u64 k = d.gtab[h].x;
-        if (k == 0ULL) return;
+        if (k == 0ULL) return false;
         if (k != key) continue;
-        if (atomicAdd((unsigned long long *)&d.gtab[(h + 1) & d.gmask].x, 0ULL) != 0ULL) { atomicExch((unsigned long long *)&d.gtab[h].x, TOMB); return; }
-        atomicExch((unsigned long long *)&d.gtab[h].x, 0ULL);
-        for (u64 b = (h - 1) & d.gmask, n = 0; n < 256; b = (b - 1) & d.gmask, ++n)
-            if (atomicCAS((unsigned long long *)&d.gtab[b].x, TOMB, 0ULL) != TOMB) break;
-        return;
+        const bool run_end = atomicAdd((unsigned long long *)&d.gtab[(h + 1) & d.gmask].x, 0ULL) == 0ULL;
+        if (atomicCAS((unsigned long long *)&d.gtab[h].x, (unsigned long long)key, run_end ? 0ULL : TOMB) != key) return false;
+        if (run_end)
+            for (u64 b = (h - 1) & d.gmask, n = 0; n < 256; b = (b - 1) & d.gmask, ++n)
+                if (atomicCAS((unsigned long long *)&d.gtab[b].x, TOMB, 0ULL) != TOMB) break;
+        return true;
     }
+    return false;
 }
 // resolve an engine-made guid to its object index, honouring lazy deletion of dead events
 __device__ __forceinline__ bool is_event_kind(u32 k) { return (k & 0x10u) != 0; }
@@ -1084,10 +1096,17 @@ __device__ __forceinline__ bool given_ok(const Dev &d, u64 g, u32 kind) {
     if (OCRGPU_GUID_KIND(g) == kind && OCRGPU_GUID_LOCATION(g) == d.location && OCRGPU_GUID_COUNTER(g) != 0) return true;
     atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return false;
 }
-__global__ void k_event_create(Dev d, u64 n, const u32 *kind, const s32 *arg, u32 first_idx, u64 first_counter, const u64 *gin, u64 *guids_out) {
+// Indices: the first `n_take` objects of a create call take the top of the free stack (`n_free` entries before the call), the
+// others fresh indices from first_idx on.
+__device__ __forceinline__ u32 take_index(const u32 *free_stack, u32 n_free, u32 n_take, u32 first_idx, u64 i) {
+    return i < n_take ? free_stack[n_free - 1u - (u32)i] : first_idx + (u32)(i - n_take);
+}
+__global__ void k_event_create(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n, const u32 *kind, const s32 *arg, u32 first_idx, u64 first_counter,
+                               const u64 *gin, u64 *guids_out) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u32 k = kind[i], x = first_idx + (u32)i;
+    u32 k = kind[i], x = take_index(rc.free_evt, n_free, n_take, first_idx, i);
+    rc.evt_guids[x] = 0;
     const u32 hi = 0; s32 arg_val = 0;
     if (k == OCREVT_COUNTED) { // nbDeps > 0 (hc-event.c:1600-1612); the count lives in counted[x]
         if (arg[i] <= 0) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return; }
@@ -1106,12 +1125,14 @@ __global__ void k_event_create(Dev d, u64 n, const u32 *kind, const s32 *arg, u3
     u64 g = gin ? gin[i] : mkguid(d.location, evt_kind_to_guid_kind(k), first_counter + i);
     if (gin && !given_ok(d, g, evt_kind_to_guid_kind(k))) return;
     gtab_put(d, g, (u64)x + 1);
+    rc.evt_guids[x] = g;
     if (guids_out) guids_out[i] = g;
 }
-__global__ void k_db_create(Dev d, u64 n, const u64 *value, const u64 *tag, u32 first_idx, u64 first_counter, const u64 *gin, u64 *guids_out) {
+__global__ void k_db_create(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n, const u64 *value, const u64 *tag, u32 first_idx, u64 first_counter,
+                            const u64 *gin, u64 *guids_out) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u32 x = first_idx + (u32)i;
+    u32 x = take_index(rc.free_db, n_free, n_take, first_idx, i);
     d.db[x] = make_ulonglong2(value[i], tag ? tag[i] : (u64)x);
     u64 g = gin ? gin[i] : mkguid(d.location, OCRGPU_KIND_DB, first_counter + i);
     // a given DB guid may name another policy domain's DB: this entry is then the local copy of it that satisfies
@@ -1126,14 +1147,15 @@ __global__ void k_ovf_counts(u64 n, const u32 *depc, u32 *ovf) {
     if (i < n) ovf[i] = depc[i] > INLINE_SLOTS ? depc[i] : 0u;
 }
 // slot_ovf[] already holds the exclusive scan of the overflow counts (+ overflow slots in use)
-__global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, const u64 *param0, const u32 *slot_ovf,
+__global__ void k_edt_create(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n, const u32 *depc, const u32 *body, const u64 *param0, const u32 *slot_ovf,
                              u32 first_idx, u64 first_counter, const u64 *gin, const u64 *oevt_in,
                              u64 *guids_out, u64 *outevt_out, u64 *outdb_out) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    u32 e = first_idx + (u32)i, dc = depc[i], b = body[i] & 0xFFFFu;
+    u32 e = take_index(rc.free_edt, n_free, n_take, first_idx, i), dc = depc[i], b = body[i] & 0xFFFFu;
+    EdtGuids eg = {0, 0, 0, 0};
     if (d.ctrl->dbl && dc > LOCKABLE_MAX_DEPC) { // acq_walk / release_all are quadratic in depc: refuse what would not finish (the EDT does not exist)
-        atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); EdtLine Z; memset(&Z, 0, sizeof Z); Z.out_state = (u32)ST_ABSENT; d.edt[e] = Z;
+        atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); EdtLine Z; memset(&Z, 0, sizeof Z); Z.out_state = (u32)ST_ABSENT; d.edt[e] = Z; rc.edt_guids[e] = eg;
         if (!gin) { guids_out[i] = 0; if (outevt_out) outevt_out[i] = 0; if (outdb_out) outdb_out[i] = 0; }
         return;
     }
@@ -1146,8 +1168,8 @@ __global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, con
     if (dc > INLINE_SLOTS) L.slot[0] = slot_ovf[i];
     d.edt[e] = L;
     if (gin) { // caller-chosen guids: the EDT's, and (optionally) its output event's; no guid for an output DB
-        if (given_ok(d, gin[i], OCRGPU_KIND_EDT)) gtab_put(d, gin[i], (u64)e + 1);
-        if ((b & OCRBODY_F_OUTEVT) && oevt_in && oevt_in[i] && given_ok(d, oevt_in[i], OCRGPU_KIND_EVT_ONCE)) gtab_put(d, oevt_in[i], (u64)(d.max_evt + e) + 1);
+        if (given_ok(d, gin[i], OCRGPU_KIND_EDT)) { gtab_put(d, gin[i], (u64)e + 1); eg.edt = gin[i]; }
+        if ((b & OCRBODY_F_OUTEVT) && oevt_in && oevt_in[i] && given_ok(d, oevt_in[i], OCRGPU_KIND_EVT_ONCE)) { gtab_put(d, oevt_in[i], (u64)(d.max_evt + e) + 1); eg.oevt = oevt_in[i]; }
     } else {
         u64 g = mkguid(d.location, OCRGPU_KIND_EDT, first_counter + 3 * i);
         gtab_put(d, g, (u64)e + 1);
@@ -1161,7 +1183,9 @@ __global__ void k_edt_create(Dev d, u64 n, const u32 *depc, const u32 *body, con
         u64 gd = mkguid(d.location, OCRGPU_KIND_DB, first_counter + 3 * i + 2);
         gtab_put(d, gd, (u64)(d.max_db + e) + 1);
         if (outdb_out) outdb_out[i] = gd;
+        eg.edt = g; eg.oevt = ge; eg.odb = gd;
     }
+    rc.edt_guids[e] = eg;
     if (dc == 0) { u32 ri = atomicAdd(&d.ctrl->r_tail, 1u); d.fired[ri] = e; } // fires at creation (hc-task.c:1129-1134)
 }
 
@@ -1596,6 +1620,117 @@ __global__ void k_guid_remove(Dev d, u64 n, const u64 *g) {
     if (i < n && g[i] != 0 && g[i] < TOMB - 1) gtab_remove(d, g[i]);
 }
 
+// ---- reclaiming capacity ---------------------------------------------------------------------------------------
+// ocrDbDestroy (regular-datablock.c:388-470 region -> PD_MSG_GUID_DESTROY): the guid stops resolving and the index goes on the
+// free stack; for the output datablock of a HASH EDT (it lives in the EDT's line) the line is marked, and is taken back by
+// the next ocrgpu_reclaim.  Consumers that still hold the index in a pre-slot would read the next tenant: as in the
+// reference, destroying a datablock somebody is still to use is the program's error.
+__global__ void k_db_destroy(Dev d, ReclDev rc, u32 n_free, u32 n_db, u64 n, const u64 *g) {
+    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 v = gtab_get(d, g[i]);
+    if (!v || OCRGPU_GUID_KIND(g[i]) != OCRGPU_KIND_DB) { bad_op(d); return; }
+    if (!gtab_remove(d, g[i])) return; // named twice in this batch: the other element takes it back
+    const u32 idx = (u32)(v - 1);
+    if (idx >= d.max_db) { atomicOr(&d.edt[idx - d.max_db].body, BODY_DB_DEAD); return; }
+    if (idx < n_db) rc.free_db[n_free + atomicAdd(&rc.cnt[RC_DB], 1u)] = idx; // (proxy copies at the top of db[] go with Ctrl.proxy_used)
+}
+// EDTs that still wait for pre-slots and track a frontier (held-back COUNTED registrations): while there are any, lazy_tab is
+// in use and lines that used it stay where they are
+__global__ void k_reclaim_lazy_users(Dev d, ReclDev rc, u32 n_edt) {
+    u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    if (e < n_edt) {
+        const uint4 h = *reinterpret_cast<const uint4 *>(&d.edt[e]); // pending, depc, body, out_state
+        live = !(h.z & BODY_FREE) && (h.x & PEND_LAZY) && (h.x & (h.y <= INLINE_SLOTS ? PEND_INL_CNT : PEND_MASK)) != 0;
+    }
+    const u64 m = __ballot(live);
+    if (m && lane_id() == (u32)(__ffsll((long long)m) - 1)) atomicAdd(&rc.cnt[RC_LAZY_LIVE], (u32)__popcll(m));
+}
+// One thread per entry of held[0,n_held) and of the ready log fired[0,r_end): an EDT that has fired, whose body has run (host
+// bodies: handed out by ocrgpu_pop_ready before this call), whose ONCE output event is gone and whose output datablock has
+// been destroyed gives its line and its guids back (destructTaskHc, hc-task.c:721-790).  What cannot go yet is kept in
+// held_new; host-body EDTs not handed out yet stay in the ready log (`unpopped`).
+__global__ void k_reclaim_edts(Dev d, ReclDev rc, u32 n_held, u32 r_end, u32 pop_cursor, u32 n_free, u32 *unpopped) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= (u64)n_held + r_end) return;
+    const bool from_log = i >= n_held;
+    const u32 e = from_log ? d.fired[i - n_held] : rc.held[i];
+    if (e == INVALID) return;
+    const uint4 h = *reinterpret_cast<const uint4 *>(&d.edt[e]);
+    const u32 pending = h.x, body = h.z, out_state = h.w, kind = OCRBODY_KIND(body);
+    if (body & BODY_FREE) return;
+    if (kind == OCRBODY_HOST && from_log && i - n_held >= pop_cursor) { unpopped[atomicAdd(&rc.cnt[RC_UNPOPPED], 1u)] = e; return; }
+    bool ok = true;
+    if ((body & OCRBODY_F_OUTEVT) && (out_state & 0xFF) != ST_DESTROYED) ok = false;   // its output event has not fired yet
+    if (kind == OCRBODY_HASH && !(body & BODY_DB_DEAD)) ok = false;                     // its output datablock is still alive
+    if ((pending & PEND_LAZY) && rc.cnt[RC_LAZY_LIVE] != 0) ok = false;                 // lazy_tab entries of this line cannot be dropped yet
+    if (!ok) { rc.held_new[atomicAdd(&rc.cnt[RC_HELD], 1u)] = e; return; }
+    const EdtGuids g = rc.edt_guids[e];
+    if (g.edt) gtab_remove(d, g.edt);
+    if (g.oevt) gtab_remove(d, g.oevt);
+    if (g.odb) gtab_remove(d, g.odb);
+    rc.edt_guids[e] = EdtGuids{0, 0, 0, 0};
+    if (pending & PEND_LAZY) atomicAdd(&rc.cnt[RC_LAZY_FREED], 1u);
+    *reinterpret_cast<uint4 *>(&d.edt[e]) = make_uint4(0u, h.y, BODY_FREE, (u32)ST_ABSENT);
+    rc.free_edt[n_free + atomicAdd(&rc.cnt[RC_EDT], 1u)] = e;
+}
+// destructEventHc (hc-event.c:185-242): a destroyed event's record and guid go back
+__global__ void k_reclaim_evts(Dev d, ReclDev rc, u32 n_evt, u32 n_free) {
+    const u32 x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n_evt || (d.evt[x].state_kind & 0xFF) != ST_DESTROYED) return;
+    const u64 g = rc.evt_guids[x];
+    if (g) gtab_remove(d, g);
+    rc.evt_guids[x] = 0;
+    d.evt[x].state_kind = (u32)ST_ABSENT;
+    rc.free_evt[n_free + atomicAdd(&rc.cnt[RC_EVT], 1u)] = x;
+}
+// what the bump-allocated pools (overflow pre-slots, script ops) still serve: none left = the pool starts over
+__global__ void k_reclaim_pool_users(Dev d, ReclDev rc, u32 n_edt) {
+    u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ovf = false, scr = false;
+    if (e < n_edt) {
+        const uint4 h = *reinterpret_cast<const uint4 *>(&d.edt[e]);
+        if (!(h.z & BODY_FREE)) { ovf = h.y > INLINE_SLOTS; scr = (h.z & BODY_F_SCRIPT) != 0; }
+    }
+    const u64 mo = __ballot(ovf), ms = __ballot(scr);
+    if (lane_id() == 0) { if (mo) atomicAdd(&rc.cnt[RC_OVF_LIVE], (u32)__popcll(mo)); if (ms) atomicAdd(&rc.cnt[RC_SCRIPT_LIVE], (u32)__popcll(ms)); }
+}
+// The registration log keeps the entries whose source event is still LIVE -- exactly what seal() would build rows from --
+// in their order (flags -> scan -> scatter into a copy -> back).  Entries of fired or destroyed sources would otherwise
+// come back to life under the next tenant of the source's index.
+__global__ void k_log_flags(Dev d, u32 *flags) {
+    u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        flags[i] = (*evt_state(d, d.log_src[i]) & 0xFF) == ST_LIVE ? 1u : 0u;
+}
+__global__ void k_log_scatter(Dev d, const u32 *flags, const u32 *pos, u32 *tsrc, u64 *trec) {
+    u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (flags[i]) { tsrc[pos[i]] = d.log_src[i]; trec[pos[i]] = d.log_rec[i]; }
+}
+__global__ void k_log_back(Dev d, const u32 *tsrc, const u64 *trec, const u32 *kept) {
+    const u32 n = *kept;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { d.log_src[i] = tsrc[i]; d.log_rec[i] = trec[i]; }
+}
+// The ready log starts over: [host-body EDTs that fired but were not handed out yet][EDTs that are ready and have not fired].
+__global__ void k_ready_gather(Dev d, ReclDev rc, u32 r_end, u32 r_tail, u32 *ready) {
+    for (u64 i = r_end + blockIdx.x * (u64)blockDim.x + threadIdx.x; i < r_tail; i += (u64)gridDim.x * blockDim.x) {
+        const u32 e = d.fired[i];
+        if (e != INVALID) ready[atomicAdd(&rc.cnt[RC_READY], 1u)] = e;
+    }
+}
+__global__ void k_ready_back(Dev d, ReclDev rc, const u32 *unpopped, const u32 *ready) {
+    const u32 nu = rc.cnt[RC_UNPOPPED], n = nu + rc.cnt[RC_READY];
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d.fired[i] = i < nu ? unpopped[i] : ready[i - nu];
+}
+__global__ void k_reclaim_finish(Dev d, ReclDev rc, u32 compact_log) {
+    Ctrl *c = d.ctrl;
+    c->r_end = rc.cnt[RC_UNPOPPED]; c->r_tail = rc.cnt[RC_UNPOPPED] + rc.cnt[RC_READY];
+    c->level = 0xFFFFFFFFu; c->n_levels = 0; c->b_begin = c->b_end = 0; // level numbering starts over with the log
+    if (compact_log) c->log_tail = rc.cnt[RC_LOG_KEPT];
+}
+
 // ---- result readback ------------------------------------------------------------------------------------
 __global__ void k_fill_i32(s32 *p, u64 n, s32 v) { u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 __global__ void k_levels(Dev d, u64 first, u64 n, s32 *level_out) {
@@ -1646,7 +1781,7 @@ static thread_local char g_err[512] = "";
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
 struct Snapshot { DbLock *dbl; EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; u64 *chan_wait; u32 *chan_sat; u32 chan_wait_used, chan_sat_used; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries;
-                  u64 edges_upper, seal_epoch, err_seen; bool valid; };
+                  u64 edges_upper, seal_epoch, err_seen, mut_epoch; bool valid; };
 static void snap_free(Snapshot &s) {
     if (s.dbl) (void)hipFree(s.dbl);
     s.dbl = nullptr;
@@ -1675,6 +1810,9 @@ struct ocrgpu_engine {
     // comm-platform over RCCL (ocrgpu_comm_*): communicator of this partition, receive regions, a small device word block
     void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records; u64 *xsum_dev;
     u64 *wp; u64 wp_cap, wp_head, wp_tail; // workpile: ring of guids in HBM, indices kept by the (single) caller side
+    // reclaimed capacity (ocrgpu_reclaim, ocrgpu_db_destroy): device tables, host mirrors of the free-stack heights and of the
+    // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
+    ReclDev rc; u32 n_free_edt, n_free_evt, n_free_db, n_held; u64 mut_epoch; char *recl_tmp; size_t recl_tmp_cap;
 };
 
 static int dalloc(ocrgpu_engine *e, void **p, size_t bytes, bool zero = true) {
@@ -1758,7 +1896,7 @@ static int scan_u32(ocrgpu_engine *e, const u32 *in, u32 *out, u64 n, u32 add0, 
 }
 
 static int scratch_setup(int device);
-extern "C" int ocrgpu_abi_version(void) { return 2; }
+extern "C" int ocrgpu_abi_version(void) { return 3; }
 extern "C" const char *ocrgpu_last_error(void) { return g_err; }
 
 extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_config_t *cfg) {
@@ -1775,6 +1913,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
     e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0; e->xsum_dev = nullptr;
     e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
+    memset(&e->rc, 0, sizeof e->rc); e->n_free_edt = e->n_free_evt = e->n_free_db = e->n_held = 0; e->mut_epoch = 0; e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->seal_epoch = 0; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->snap.dbl = nullptr; e->have_events = false;
@@ -1837,6 +1976,14 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&e->tmp_a, 4 * (size_t)(tmpn + 4)));
     TRY(dalloc(e, (void **)&e->tmp_b, 4 * (size_t)(tmpn + 4)));
     TRY(dalloc(e, (void **)&e->tmp_c, 4 * (size_t)(tmpn + 4)));
+    TRY(dalloc(e, (void **)&e->rc.edt_guids, sizeof(EdtGuids) * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&e->rc.evt_guids, 8 * (size_t)cfg->max_evt));
+    TRY(dalloc(e, (void **)&e->rc.free_edt, 4 * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&e->rc.free_evt, 4 * (size_t)cfg->max_evt));
+    TRY(dalloc(e, (void **)&e->rc.free_db, 4 * (size_t)cfg->max_db));
+    TRY(dalloc(e, (void **)&e->rc.held, 4 * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&e->rc.held_new, 4 * (size_t)cfg->max_edt));
+    TRY(dalloc(e, (void **)&e->rc.cnt, 4 * RC_N));
     // ctrl.level starts at -1 (main-program satisfies are "level -1")
     Ctrl h; memset(&h, 0, sizeof h); h.level = 0xFFFFFFFFu; h.state[0].done = h.state[1].done = 1;
     h.dbl = e->dbl; h.acq_mode = e->acq_mode;
@@ -1888,6 +2035,7 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stage_dev) (void)hipFree(e->stage_dev);
     if (e->scan_partials) (void)hipFree(e->scan_partials);
+    if (e->recl_tmp) (void)hipFree(e->recl_tmp);
     if (e->snap.valid) snap_free(e->snap);
     if (e->pinned_done) (void)hipHostFree(e->pinned_done);
     for (int i = 0; i < 2; ++i) if (e->apply_ev[i]) (void)hipEventDestroy(e->apply_ev[i]);
@@ -2054,15 +2202,16 @@ extern "C" int ocrgpu_event_create(ocrgpu_engine_t *e, u64 n, const u32 *kind, c
     ENTER(e);
     if (n == 0) return 0;
     if (!kind || !arg || !guids_out) FAIL(OCRGPU_EINVAL, "null array");
-    if ((u64)e->n_evt + n > e->cfg.max_evt) FAIL(OCRGPU_ENOMEM, "max_evt=%u exhausted", e->cfg.max_evt);
+    const u32 take = n < e->n_free_evt ? (u32)n : e->n_free_evt; // reclaimed records first
+    if ((u64)e->n_evt + (n - take) > e->cfg.max_evt) FAIL(OCRGPU_ENOMEM, "max_evt=%u exhausted (%u reclaimed records free)", e->cfg.max_evt, e->n_free_evt);
     const bool given = (where & OCRGPU_GUIDS_GIVEN) != 0; where &= 1;
     int r = stage_reserve(e, 2 * rup(4 * n) + rup(8 * n)); if (r) return r;
     const u32 *dk; const s32 *da; u64 *dg = nullptr; const u64 *dgin = nullptr;
     if ((r = stage_in(e, kind, n, where, &dk)) || (r = stage_in(e, arg, n, where, &da))) return r;
     if (given) r = stage_in(e, (const u64 *)guids_out, n, where, &dgin); else r = stage_out_alloc(e, guids_out, n, where, &dg);
     if (r) return r;
-    k_event_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dk, da, e->n_evt, e->counter, dgin, dg);
-    e->n_evt += (u32)n; if (!given) e->counter += n;
+    k_event_create<<<nblk(n), 256, 0, e->stream>>>(e->d, e->rc, e->n_free_evt, take, n, dk, da, e->n_evt, e->counter, dgin, dg);
+    e->n_evt += (u32)(n - take); e->n_free_evt -= take; if (take) ++e->mut_epoch; if (!given) e->counter += n;
     if (!given && (r = stage_out_copy(e, guids_out, dg, n, where))) return r;
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
@@ -2071,15 +2220,16 @@ extern "C" int ocrgpu_db_create(ocrgpu_engine_t *e, u64 n, const u64 *value, con
     ENTER(e);
     if (n == 0) return 0;
     if (!value || !guids_out) FAIL(OCRGPU_EINVAL, "null array");
-    if ((u64)e->n_db + n > e->cfg.max_db) FAIL(OCRGPU_ENOMEM, "max_db=%u exhausted", e->cfg.max_db);
+    const u32 take = n < e->n_free_db ? (u32)n : e->n_free_db;
+    if ((u64)e->n_db + (n - take) > e->cfg.max_db) FAIL(OCRGPU_ENOMEM, "max_db=%u exhausted (%u destroyed datablocks free)", e->cfg.max_db, e->n_free_db);
     const bool given = (where & OCRGPU_GUIDS_GIVEN) != 0; where &= 1;
     int r = stage_reserve(e, 3 * rup(8 * n)); if (r) return r;
     const u64 *dv, *dt; u64 *dg = nullptr; const u64 *dgin = nullptr;
     if ((r = stage_in(e, value, n, where, &dv)) || (r = stage_in(e, tag, n, where, &dt))) return r;
     if (given) r = stage_in(e, (const u64 *)guids_out, n, where, &dgin); else r = stage_out_alloc(e, guids_out, n, where, &dg);
     if (r) return r;
-    k_db_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dv, dt, e->n_db, e->counter, dgin, dg);
-    e->n_db += (u32)n; if (!given) e->counter += n;
+    k_db_create<<<nblk(n), 256, 0, e->stream>>>(e->d, e->rc, e->n_free_db, take, n, dv, dt, e->n_db, e->counter, dgin, dg);
+    e->n_db += (u32)(n - take); e->n_free_db -= take; if (take) ++e->mut_epoch; if (!given) e->counter += n;
     if (!given && (r = stage_out_copy(e, guids_out, dg, n, where))) return r;
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
@@ -2089,7 +2239,8 @@ extern "C" int ocrgpu_edt_create(ocrgpu_engine_t *e, u64 n, const u32 *depc, con
     ENTER(e);
     if (n == 0) return 0;
     if (!depc || !body || !guids_out) FAIL(OCRGPU_EINVAL, "null array");
-    if ((u64)e->n_edt + n > e->cfg.max_edt) FAIL(OCRGPU_ENOMEM, "max_edt=%u exhausted", e->cfg.max_edt);
+    const u32 take = n < e->n_free_edt ? (u32)n : e->n_free_edt;
+    if ((u64)e->n_edt + (n - take) > e->cfg.max_edt) FAIL(OCRGPU_ENOMEM, "max_edt=%u exhausted (%u reclaimed lines free)", e->cfg.max_edt, e->n_free_edt);
     const bool given = (where & OCRGPU_GUIDS_GIVEN) != 0; where &= 1;
     int r = stage_reserve(e, 4 * rup(4 * n) + 4 * rup(8 * n) + 256); if (r) return r;
     const u32 *dd, *db; const u64 *dp; u64 *dg = nullptr, *doe = nullptr, *dod = nullptr; u32 *dsb, *dtot; const u64 *dgin = nullptr, *doin = nullptr;
@@ -2107,8 +2258,8 @@ extern "C" int ocrgpu_edt_create(ocrgpu_engine_t *e, u64 n, const u32 *depc, con
     HIPCHK(hipStreamSynchronize(e->stream));
     u64 add = e->pinned_done[33000] - (u32)e->n_slots; // the scan was seeded with the slots already in use
     if (e->n_slots + add > e->d.max_slots) FAIL(OCRGPU_ENOMEM, "max_slots=%llu exhausted", (unsigned long long)e->d.max_slots);
-    k_edt_create<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dd, db, dp, dsb, e->n_edt, e->counter, dgin, doin, dg, doe, dod);
-    e->n_edt += (u32)n; e->n_slots += add; if (!given) e->counter += 3 * n;
+    k_edt_create<<<nblk(n), 256, 0, e->stream>>>(e->d, e->rc, e->n_free_edt, take, n, dd, db, dp, dsb, e->n_edt, e->counter, dgin, doin, dg, doe, dod);
+    e->n_edt += (u32)(n - take); e->n_free_edt -= take; if (take) ++e->mut_epoch; e->n_slots += add; if (!given) e->counter += 3 * n;
     if (!given && ((r = stage_out_copy(e, guids_out, dg, n, where)) || (r = stage_out_copy(e, outevt_out, doe, n, where)) ||
                    (r = stage_out_copy(e, outdb_out, dod, n, where)))) return r;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -2201,6 +2352,91 @@ extern "C" int ocrgpu_event_destroy(ocrgpu_engine_t *e, u64 n, const u64 *evt, i
     HIPCHK(hipGetLastError());
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
+}
+
+// ---- reclaiming capacity ------------------------------------------------------------------------------------------
+extern "C" int ocrgpu_db_destroy(ocrgpu_engine_t *e, u64 n, const u64 *guids, int where) {
+    ENTER(e);
+    if (n == 0) return 0;
+    if (!guids) FAIL(OCRGPU_EINVAL, "null array");
+    int r = stage_reserve(e, rup(8 * n)); if (r) return r;
+    const u64 *dg; if ((r = stage_in(e, guids, n, where, &dg))) return r;
+    HIPCHK(hipMemsetAsync(e->rc.cnt + RC_DB, 0, 4, e->stream));
+    k_db_destroy<<<nblk(n), 256, 0, e->stream>>>(e->d, e->rc, e->n_free_db, e->n_db, n, dg);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33016, e->rc.cnt + RC_DB, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + PIN_ERR, e->d.ctrl->err, 32, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream)); // the free stack's height is the host's to know
+    e->n_free_db += e->pinned_done[33016]; ++e->mut_epoch;
+    return check_fault(e);
+}
+extern "C" int ocrgpu_reclaim(ocrgpu_engine_t *e, ocrgpu_reclaim_t *out) {
+    ENTER(e);
+    Dev &d = e->d; const ReclDev &rc = e->rc;
+    // quiescence: no satisfy record may be in flight (a record names its destination by index)
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33008, &d.ctrl->q_begin, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33009, &d.ctrl->q_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int fault = 0;
+    if (e->pinned_done[33009] > e->pinned_done[33008]) {
+        if (e->defer_drain) FAIL(OCRGPU_EINVAL, "ocrgpu_reclaim: satisfy records are pending (call ocrgpu_step first)");
+        int r = run_steps(e, 0u, ~0ull, false); if (r) return r;
+        fault = check_fault(e);
+    }
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33010, &d.ctrl->r_end, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33011, &d.ctrl->r_tail, 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const u32 r_end = e->pinned_done[33010], r_tail = e->pinned_done[33011];
+    const u32 pop_cursor = e->pop_cursor < r_end ? e->pop_cursor : r_end;
+    HIPCHK(hipMemsetAsync(rc.cnt, 0, 4 * RC_N, e->stream));
+    if (e->n_edt) k_reclaim_lazy_users<<<nblk(e->n_edt), 256, 0, e->stream>>>(d, rc, e->n_edt);
+    const u64 n_cand = (u64)e->n_held + r_end;
+    if (n_cand) k_reclaim_edts<<<nblk(n_cand), 256, 0, e->stream>>>(d, rc, e->n_held, r_end, pop_cursor, e->n_free_edt, e->tmp_a);
+    if (e->n_evt) k_reclaim_evts<<<nblk(e->n_evt), 256, 0, e->stream>>>(d, rc, e->n_evt, e->n_free_evt);
+    if (e->n_edt) k_reclaim_pool_users<<<nblk(e->n_edt), 256, 0, e->stream>>>(d, rc, e->n_edt);
+    // the registration log (the rows are rebuilt from it by the next run)
+    const u64 nl = e->edges_upper;
+    if (nl) {
+        const size_t need = 2 * rup(4 * nl) + rup(4 * nl) + rup(8 * nl);
+        if (need > e->recl_tmp_cap) {
+            HIPCHK(hipStreamSynchronize(e->stream));
+            if (e->recl_tmp) HIPCHK(hipFree(e->recl_tmp));
+            e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
+            HIPCHK(hipMalloc((void **)&e->recl_tmp, need + need / 4));
+            e->recl_tmp_cap = need + need / 4;
+        }
+        u32 *flags = (u32 *)e->recl_tmp, *pos = (u32 *)(e->recl_tmp + rup(4 * nl)), *tsrc = (u32 *)(e->recl_tmp + 2 * rup(4 * nl));
+        u64 *trec = (u64 *)(e->recl_tmp + 3 * rup(4 * nl));
+        HIPCHK(hipMemsetAsync(flags, 0, 4 * nl, e->stream)); // entries past Ctrl.log_tail (calls that registered nothing) count as dropped
+        u32 g = nblk(nl); if (g > 4096) g = 4096;
+        k_log_flags<<<g, 256, 0, e->stream>>>(d, flags);
+        int r = scan_u32(e, flags, pos, nl, 0, rc.cnt + RC_LOG_KEPT); if (r) return r;
+        k_log_scatter<<<g, 256, 0, e->stream>>>(d, flags, pos, tsrc, trec);
+        k_log_back<<<g, 256, 0, e->stream>>>(d, tsrc, trec, rc.cnt + RC_LOG_KEPT);
+    }
+    // the ready log
+    if (r_tail > r_end) { u32 g = nblk(r_tail - r_end); if (g > 4096) g = 4096; k_ready_gather<<<g, 256, 0, e->stream>>>(d, rc, r_end, r_tail, e->tmp_b); }
+    k_ready_back<<<1024, 256, 0, e->stream>>>(d, rc, e->tmp_a, e->tmp_b);
+    k_reclaim_finish<<<1, 1, 0, e->stream>>>(d, rc, nl ? 1u : 0u);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(e->pinned_done + 33950, rc.cnt, 4 * RC_N, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const u32 *c = e->pinned_done + 33950;
+    e->n_free_edt += c[RC_EDT]; e->n_free_evt += c[RC_EVT];
+    e->n_held = c[RC_HELD]; std::swap(e->rc.held, e->rc.held_new);
+    if (nl) e->edges_upper = c[RC_LOG_KEPT];
+    e->pop_cursor = 0; e->csr_dirty = true; ++e->mut_epoch;
+    if (c[RC_OVF_LIVE] == 0) e->n_slots = 0;     // no EDT left that keeps pre-slot words outside its line
+    if (c[RC_SCRIPT_LIVE] == 0) e->n_script = 0; // nor one with a script
+    if (c[RC_LAZY_FREED] && c[RC_LAZY_LIVE] == 0) HIPCHK(hipMemsetAsync(d.lazy_tab, 0, 16 * (size_t)e->lazy_cap, e->stream));
+    memset(e->pinned_done, 0, sizeof(State)); ((State *)e->pinned_done)->done = 1; // ocrgpu_step_info: nothing fired since
+    if (out) {
+        out->edts_freed = c[RC_EDT]; out->events_freed = c[RC_EVT]; out->edts_held = c[RC_HELD]; out->edges_kept = e->edges_upper;
+        out->free_edt = e->n_free_edt; out->free_evt = e->n_free_evt; out->free_db = e->n_free_db;
+        out->fresh_edt = e->cfg.max_edt - e->n_edt; out->fresh_evt = e->cfg.max_evt - e->n_evt; out->fresh_db = e->cfg.max_db - e->n_db;
+        out->slots_used = e->n_slots; out->ready_kept = c[RC_UNPOPPED] + c[RC_READY];
+    }
+    return fault;
 }
 
 // Host-run bodies (OCRBODY_HOST) under OCRGPU_F_LOCKABLE_DB: the EDTs named have run; what they hold is released.
@@ -2735,7 +2971,7 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     HIPCHK(hipMalloc((void **)&s.fired, 4 * (size_t)s.n_fired_entries + 16));
     HIPCHK(hipMalloc((void **)&s.ctrl, sizeof(Ctrl)));
     s.valid = true; s.n_edt = e->n_edt; s.n_evt = e->n_evt; s.n_db = e->n_db; e->snap_pop_cursor = e->pop_cursor;
-    s.edges_upper = e->edges_upper; s.seal_epoch = e->seal_epoch; s.err_seen = e->err_seen;
+    s.edges_upper = e->edges_upper; s.seal_epoch = e->seal_epoch; s.err_seen = e->err_seen; s.mut_epoch = e->mut_epoch;
     HIPCHK(hipMemcpyAsync(s.edt, d.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(s.evt, d.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
     if (e->n_evt) HIPCHK(hipMemcpyAsync(s.counted, d.counted, 8 * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));
@@ -2749,7 +2985,7 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     ENTER(e);
     Dev &d = e->d; Snapshot &s = e->snap;
     if (!s.valid) FAIL(OCRGPU_EINVAL, "no snapshot taken");
-    if (s.n_edt != e->n_edt || s.n_evt != e->n_evt) FAIL(OCRGPU_EINVAL, "objects were created after the snapshot");
+    if (s.n_edt != e->n_edt || s.n_evt != e->n_evt || s.mut_epoch != e->mut_epoch) FAIL(OCRGPU_EINVAL, "objects were created or reclaimed after the snapshot");
     e->pop_cursor = e->snap_pop_cursor;
     e->n_db = s.n_db; // (proxy datablocks cloned from other partitions since the snapshot go with Ctrl.proxy_used)
     // the registration log is append-only and Ctrl.log_tail goes back with Ctrl: what was registered since the snapshot is

@@ -206,6 +206,8 @@ static void sort_ops(void) {
     free(cnt);
 }
 
+static u64 g_max_edges;
+static u64 cap_edges_now(void) { return g_max_edges; }
 static u64 *bu64[4]; static u32 *bu32[3]; static s32 *bs32; static size_t bcap;
 static void batch_room(size_t n) {
     if (n <= bcap) return;
@@ -215,10 +217,41 @@ static void batch_room(size_t n) {
     bs32 = xrealloc(bs32, 4 * bcap);
 }
 
+/* Engine capacity is what is alive (the reference frees an EDT when its body has returned, hc-task.c:721, an event when it
+ * is destroyed, hc-event.c:185-242, a datablock on ocrDbDestroy): when the queue holds more creates than the engine has rows
+ * left, the rows of finished EDTs and destroyed events are taken back first (ocrgpu_reclaim).  Only between levels and with
+ * no body on the stack (a body blocked in ocrLegacyBlockProgress has been handed out but has not returned). */
+static u64 room[4];               /* rows / registrations the engine can still take: EDTs, events, datablocks, edges */
+static int run_depth;             /* bodies on the stack */
+static u64 n_reclaims, peak_live_edt, cap_edt;
+static void make_room(void) {
+    u64 want[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n_ops; ++i)
+        switch (ops[i].cls) {
+        case C_EDT_CREATE: ++want[0]; break;
+        case C_EVT_CREATE: ++want[1]; break;
+        case C_DB_CREATE: ++want[2]; break;
+        case C_ADD_DEP: ++want[3]; break;
+        default: break;
+        }
+    int short_of = 0;
+    for (int k = 0; k < 4; ++k) if (want[k] > room[k]) short_of = 1;
+    if (short_of && run_depth == 0) {
+        ocrgpu_reclaim_t r; memset(&r, 0, sizeof r);
+        CHK(ocrgpu_reclaim(G, &r));
+        ++n_reclaims;
+        room[0] = r.free_edt + r.fresh_edt; room[1] = r.free_evt + r.fresh_evt; room[2] = r.free_db + r.fresh_db;
+        room[3] = cap_edges_now() - r.edges_kept;
+    }
+    if (cap_edt - room[0] + want[0] > peak_live_edt) peak_live_edt = cap_edt - room[0] + want[0];
+    for (int k = 0; k < 4; ++k) room[k] = room[k] > want[k] ? room[k] - want[k] : 0; /* short after all: the create call reports it */
+}
+
 /* apply the queue: one C-ABI call per (round, class) */
 static void flush(void) {
     ++flush_epoch;
     if (!n_ops) return;
+    make_room();
     double ts0 = now_s();
     sort_ops();
     t_sort += now_s() - ts0; ts0 = now_s();
@@ -258,7 +291,8 @@ static void flush(void) {
             break;
         case C_DB_DESTROY:
             for (size_t k = 0; k < n; ++k) { bu64[0][k] = o[k].a; db_free(dbmap_take(o[k].a)); }
-            CHK(ocrgpu_guid_remove(G, n, bu64[0], OCRGPU_HOST));
+            CHK(ocrgpu_db_destroy(G, n, bu64[0], OCRGPU_HOST));
+            room[2] += n;
             break;
         }
         i = j;
@@ -600,6 +634,8 @@ static int shim_init(void) {
     memset(pools, 0, sizeof pools);
     if (dbmap_cap) { memset(dbmap, 0, dbmap_cap * sizeof *dbmap); dbmap_n = 0; }
     if (labset_cap) { memset(labset, 0, labset_cap * sizeof *labset); memset(labalive, 0, labset_cap); labset_n = 0; }
+    room[0] = cap_edt = cfg.max_edt; room[1] = cfg.max_evt; room[2] = cfg.max_db; room[3] = g_max_edges = cfg.max_edges;
+    run_depth = 0; n_reclaims = 0; peak_live_edt = 0;
     int rc = ocrgpu_init(&G, (int)env_u64("OCRSHIM_DEVICE", 0), &cfg);
     if (rc) { fprintf(stderr, "ocrshim: ocrgpu_init failed (%d): %s\n", rc, ocrgpu_last_error()); return 71; }
     if (!rq_cap_e) {
@@ -658,7 +694,9 @@ static int run_one(void) {
         depv[k].guid.guid = (intptr_t)rq_dg[rq_df[i] + k]; depv[k].ptr = (void *)(uintptr_t)rq_dv[rq_df[i] + k]; depv[k].mode = DB_DEFAULT_MODE;
     }
     body_begin(&t);
+    ++run_depth;
     ocrGuid_t ret = t.fn(t.paramc, t.paramv, t.depc, depv);
+    --run_depth;
     body_end(&t, (u64)ret.guid);
     if (g_lockable && t.depc) {
         if (rel_n == rel_cap) { rel_cap = rel_cap ? 2 * rel_cap : 1024; rel_g = xrealloc(rel_g, 8 * rel_cap); }
@@ -679,6 +717,9 @@ static int shim_fini(void) {
                 (unsigned long long)n_levels, (unsigned long long)n_bodies, (unsigned long long)st.edt_sat, (unsigned long long)st.evt_sat,
                 (unsigned long long)st.err[0], (unsigned long long)st.err[1], (unsigned long long)st.err[2], (unsigned long long)st.err[3],
                 (unsigned long long)st.err[4], (unsigned long long)st.err[5], (unsigned long long)st.err[6]);
+    if (g_verbose)
+        fprintf(stderr, "ocrshim: reclaims=%llu peak_live_edt<=%llu of max_edt=%llu\n", (unsigned long long)n_reclaims,
+                (unsigned long long)peak_live_edt, (unsigned long long)cap_edt);
     if (g_verbose)
         fprintf(stderr, "ocrshim: seconds: bodies %.3f | queue sort %.3f | batched C-ABI calls %.3f | ocrgpu_step %.3f | ocrgpu_pop_ready %.3f\n",
                 t_bodies, t_sort, t_calls, t_step, t_pop);

@@ -47,6 +47,11 @@ class Config(C.Structure):
                 ("max_levels", C.c_uint32), ("flags", C.c_uint32)]
 
 
+class Reclaim(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("edts_freed", "events_freed", "edts_held", "edges_kept", "free_edt", "free_evt", "free_db",
+                                          "fresh_edt", "fresh_evt", "fresh_db", "slots_used", "ready_kept")]
+
+
 class Stats(C.Structure):
     _fields_ = [("levels", C.c_uint64), ("fired", C.c_uint64), ("edt_sat", C.c_uint64), ("evt_sat", C.c_uint64),
                 ("launches", C.c_uint64), ("step_kernel_ns", C.c_uint64), ("err", C.c_uint64 * 8)]
@@ -69,7 +74,7 @@ EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error
            "ocrgpu_read_events", "ocrgpu_read_dbs", "ocrgpu_read_fired", "ocrgpu_get_stats",
            "ocrgpu_comm_get_unique_id", "ocrgpu_comm_init", "ocrgpu_comm_fini", "ocrgpu_comm_alltoall", "ocrgpu_exchange",
            "ocrgpu_exchange_local", "ocrgpu_resolve_exchange", "ocrgpu_resolve_exchange_local", "ocrgpu_workpile_push",
-           "ocrgpu_workpile_pop"]
+           "ocrgpu_workpile_pop", "ocrgpu_db_destroy", "ocrgpu_reclaim"]
 RX_NO_CASCADE = 1
 WP_PUSH, WP_PUSHBACK, WP_POP, WP_STEAL = 0, 1, 0, 1
 
@@ -257,6 +262,17 @@ class Engine:
         evt = np.ascontiguousarray(evt, np.uint64)
         self._chk(self.lib.ocrgpu_event_destroy(self.h, C.c_uint64(len(evt)), _ptr(evt), HOST))
 
+    def db_destroy(self, guids):
+        """ocrDbDestroy: guids stop resolving, indices go back (output DBs of HASH EDTs: their EDT's line may go)."""
+        g = np.ascontiguousarray(guids, dtype=np.uint64)
+        self._chk(self.lib.ocrgpu_db_destroy(self.h, C.c_uint64(len(g)), _ptr(g), HOST))
+
+    def reclaim(self):
+        """Take back the rows of finished EDTs and destroyed events; returns ocrgpu_reclaim_t as a dict."""
+        out = Reclaim()
+        self._chk(self.lib.ocrgpu_reclaim(self.h, C.byref(out)))
+        return {n: int(getattr(out, n)) for n, _ in Reclaim._fields_}
+
     def edt_release_dbs(self, edt):
         """F_LOCKABLE_DB, host-run bodies: the EDTs named have run; release the datablocks they hold."""
         edt = np.ascontiguousarray(edt, np.uint64)
@@ -417,8 +433,14 @@ class StreamProgram:
     """An op stream loaded into an :class:`Engine`: the same role oracle/ocr_replay.c plays for the
     reference runtime, but every op becomes (part of) one batched C-ABI call."""
 
-    def __init__(self, s: OpStream, device=0, flags=0, engine=None, slack=0, tolerate_faults=False):
+    def __init__(self, s: OpStream, device=0, flags=0, engine=None, slack=0, tolerate_faults=False, reuse=False):
         self.s = s
+        # reuse: the engine may hand out reclaimed rows (ocrgpu_reclaim), so creation order is not index order: ask the
+        # GUID table for every object's index right after its create call
+        self.reuse = reuse
+        self.edt_index = np.full(s.n_edt, -1, np.int64)
+        self.evt_index = np.full(s.n_evt, -1, np.int64)
+        self.db_index = np.full(s.n_db, -1, np.int64)
         n_slots = int(s.edt["depc"].sum())
         n_adddep = int((s.main["op"] == ops.OP_ADD_DEP).sum())
         self.eng = engine or Engine(max_edt=max(s.n_edt, 1) + slack, max_evt=max(s.n_evt, 1), max_db=max(s.n_db, 1),
@@ -463,15 +485,21 @@ class StreamProgram:
                 idx = blk["a"].astype(np.int64)
                 self.evt_guid[idx] = eng.event_create(s.evt["kind"][idx], s.evt["arg"][idx])
                 self.evt_order += idx.tolist()
+                if self.reuse:
+                    self.evt_index[idx] = eng.guid_get(self.evt_guid[idx]).astype(np.int64) - 1
             elif op == ops.OP_DB_CREATE:
                 idx = blk["a"].astype(np.int64)
                 self.db_guid[idx] = eng.db_create(s.db_init[idx], idx.astype(np.uint64))
                 self.db_order += idx.tolist()
+                if self.reuse:
+                    self.db_index[idx] = eng.guid_get(self.db_guid[idx]).astype(np.int64) - 1
             elif op == ops.OP_EDT_CREATE:
                 idx = blk["a"].astype(np.int64)
                 g, oe, od = eng.edt_create(s.edt["depc"][idx], s.edt["body"][idx], idx.astype(np.uint64))
                 self.edt_guid[idx], self.evt_guid[s.n_evt + idx], self.db_guid[s.n_db + idx] = g, oe, od
                 self.edt_order += idx.tolist()
+                if self.reuse:
+                    self.edt_index[idx] = eng.guid_get(g).astype(np.int64) - 1
             elif op == ops.OP_ADD_DEP:
                 for c0, c1 in (ops.split_conflicts(ops.channel_keys(s, blk["a"])) if ops.channel_ring_slots(s) else [(0, len(blk))]):   # registrations on one CHANNEL keep program order
                     b = blk[c0:c1]
@@ -515,7 +543,27 @@ class StreamProgram:
     def resolve(self):
         return self.eng.resolve()
 
+    def _result_by_index(self) -> Result:
+        s, eng = self.s, self.eng
+        assert (self.edt_index >= 0).all() and (self.evt_index >= 0).all() and (self.db_index >= 0).all()
+        evs = np.full(s.n_evt_total, ops.EVS_ABSENT, np.uint64)
+        dbv = np.zeros(s.n_db_total, np.uint64)
+        level, v = np.zeros(0, np.int32), np.zeros(0, np.uint64)
+        if s.n_edt:
+            ne = int(self.edt_index.max()) + 1
+            lv, val = eng.read_edts(0, ne)
+            level, v = lv[self.edt_index], val[self.edt_index]
+            evs[s.n_evt:] = eng.read_events(1, 0, ne)[self.edt_index]
+            dbv[s.n_db:] = eng.read_dbs(1, 0, ne)[self.edt_index]
+        if s.n_evt:
+            evs[:s.n_evt] = eng.read_events(0, 0, int(self.evt_index.max()) + 1)[self.evt_index]
+        if s.n_db:
+            dbv[:s.n_db] = eng.read_dbs(0, 0, int(self.db_index.max()) + 1)[self.db_index]
+        return Result(level, v, evs, dbv)
+
     def result(self) -> Result:
+        if self.reuse:
+            return self._result_by_index()
         s, eng = self.s, self.eng
         lv, val = eng.read_edts(0, s.n_edt) if s.n_edt else (np.zeros(0, np.int32), np.zeros(0, np.uint64))
         eo = np.asarray(self.edt_order, dtype=np.int64)

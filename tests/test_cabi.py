@@ -13,12 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_header_and_library_agree():
     hdr = open(os.path.join(ROOT, "include", "ocrgpu.h")).read()
     declared = set(re.findall(r"\b(ocrgpu_[a-z_0-9]+)\s*\(", hdr))
-    declared -= {"ocrgpu_engine", "ocrgpu_engine_t"}
+    declared -= {"ocrgpu_engine", "ocrgpu_engine_t", "ocrgpu_reclaim_t"}
     assert declared == set(engine.EXPORTS)
     lib = engine.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ocrgpu_abi_version() == 2
+    assert lib.ocrgpu_abi_version() == 3
 
 
 def test_no_cpu_fallback():

@@ -69,3 +69,24 @@ def test_fib20():
     r = subprocess.run([exe, "20"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert r.stdout.strip() == "FIB n=20 result=6765 fib_edts=21891 sum_edts=10945"
+
+
+def test_fib27_in_an_engine_sized_for_the_live_set():
+    """fib(27) creates 953 433 EDTs (635 621 fib + 317 810 sum + root + done), but at most ~half of them are alive at any time
+    (every `sum` continuation waits for its subtree; a fib EDT is done the moment its body returns).  With OCRSHIM_MAX_EDT at
+    that live maximum -- not at the total -- libocrshim takes finished EDTs' rows back between levels (ocrgpu_reclaim) the way
+    the reference frees a task when taskExecute returns (hc-task.c:721); the datablocks the program destroys give their rows
+    back too (ocrgpu_db_destroy), so the 635 621 of them fit 420 000 rows."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from ocr_amd import build as B
+    exe = B.build_program(os.path.join(ROOT, "tests", "programs", "fib.c"))
+    env = dict(os.environ, OCRSHIM_MAX_EDT="480000", OCRSHIM_MAX_EVT="700000", OCRSHIM_MAX_DB="420000", OCRSHIM_MAX_EDGES="2000000",
+               OCRSHIM_VERBOSE="1")
+    r = subprocess.run([exe, "27"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    assert r.stdout.strip() == "FIB n=27 result=196418 fib_edts=635621 sum_edts=317810"
+    m = re.search(r"reclaims=(\d+) peak_live_edt<=(\d+) of max_edt=480000", r.stderr)
+    assert m and int(m.group(1)) >= 1 and int(m.group(2)) <= 480000, r.stderr[-800:]
+    assert "err=[0 0 0 0 0 0 0]" in r.stderr
+    print(r.stderr[-600:])
