@@ -142,7 +142,7 @@ def main():
                        "k_step_launches_per_resolve": launches, "parity": parity},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / step_kernel_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": alg_bytes / step_kernel_s / 1e9 / 8000.0,
-                         "traffic": profiled_traffic(args),
+                         "traffic": profiled_traffic(args)[0], "traffic_source": profiled_traffic(args)[1],
                          "kernel": "k_step (all launches of one resolve, HIP events on the engine stream)",
                          "launches_per_resolve": launches, "alg_bytes_per_launch": alg_bytes / launches,
                          "us_per_launch": step_kernel_s / launches * 1e6,
@@ -333,25 +333,37 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     dist.destroy_process_group()
 
 
-def profiled_traffic(args, tag="r01g_config2"):
+PROFILE_TAG = "r02a_config2"
+
+
+def profiled_traffic(args, tag=PROFILE_TAG):
     """HBM bytes per k_step launch from the committed PMC passes (profiles/<tag>_pmc_summary.txt: FETCH_SIZE and
     WRITE_SIZE in KB, separate rocprofv3 --pmc runs of this same workload).  Counters cannot be read inside this
-    process, so the figure is the profiled one; None for any other workload shape."""
+    process, so the figure is the profiled one, and it is only quoted for the workload and the engine source it was
+    taken on: the summary records a hash of ocr_amd/csrc/ocrgpu.hip, and any other source (or workload shape) gives
+    None.  Returns (bytes per launch or None, where the figure comes from)."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "profiles", tag + "_pmc_summary.txt")
     if args.n_edt != 10_000_000 or args.width != 10_000:
-        return None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tag + "_pmc_summary.txt")
-    kb = {}
+        return None, "not profiled for this workload shape"
+    kb, src = {}, None
     try:
         for line in open(path):
+            if line.startswith("source:"):
+                src = line.strip().split("=")[-1]
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 if "k_step" in line and ctr + " sum=" in line:
                     kb[ctr] = float(line.split("per dispatch ")[1].rstrip(")\n"))
+        now = hashlib.sha256(open(os.path.join(here, "ocr_amd", "csrc", "ocrgpu.hip"), "rb").read()).hexdigest()[:16]
     except OSError:
-        return None
+        return None, "no committed profile"
     if len(kb) != 2:
-        return None
+        return None, "no committed profile"
+    if src != now:
+        return None, f"profiles/{tag}_pmc_summary.txt was taken on another engine source ({src}, now {now})"
     # scattered <=64-B requests: raw values (the guide's x2 correction is for 16-B-per-lane coalesced streams only)
-    return (kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+    return (kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, f"profiles/{tag}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on this engine source, not this run)"
 
 
 def cpu_baseline(args):

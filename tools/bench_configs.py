@@ -32,6 +32,19 @@ def make(spec):
         n = a[0]
         s.edt["body"][:n] = op.BODY_NOP | op.BODY_F_OUTEVT
         return s
+    if k == "layeredperm":   # config 2's DAG with the EDT indices shuffled: a layer's lines lie all over the table, not in one 640-KB run
+        s = op.layered_dag(a[0], a[1])
+        n = a[0]
+        perm = np.random.default_rng(7).permutation(n).astype(np.uint64)
+        edt = s.edt.copy()
+        edt[perm.astype(np.int64)] = s.edt[:n]
+        s.edt[:n] = edt[:n]
+        for f in ("a", "b"):
+            r = s.main[f]
+            cls, idx = op.ref_cls(r), op.ref_idx(r)
+            m = ((cls == op.REF_EDT) | (cls == op.REF_OUTEVT) | (cls == op.REF_OUTDB)) & (idx < np.uint64(n)) & (s.main["op"] != op.OP_EDT_CREATE)
+            s.main[f][m] = (r[m] & np.uint64(0xFF00000000000000)) | perm[idx[m].astype(np.int64)]
+        return s
     if k == "lockable":   # lockable:N:width:n_db -- layered DAG + contended datablocks, run with OCRGPU_F_LOCKABLE_DB
         return op.lockable_layered(a[0], a[1], a[2])
     raise SystemExit(f"unknown workload {spec}")

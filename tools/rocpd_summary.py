@@ -3,10 +3,18 @@
 
 usage: python tools/rocpd_summary.py gpurun_out/<tag> profiles/<tag>
 """
+import hashlib
 import json
 import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """What bench.py compares before it quotes a profile: the engine source the profiled library was built from."""
+    return hashlib.sha256(open(os.path.join(ROOT, "ocr_amd", "csrc", "ocrgpu.hip"), "rb").read()).hexdigest()[:16]
 
 
 def kernel_stats(db_path, out_csv):
@@ -36,7 +44,7 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     rows = kernel_stats(os.path.join(src, "trace", "trace_results.db"), dst + "_kernel_stats.csv")
-    lines = []
+    lines = ["source: ocr_amd/csrc/ocrgpu.hip sha256[:16]=" + kernel_source_hash()]
     bench = json.loads(open(os.path.join(src, "trace.json")).read().strip().splitlines()[-1])
     lines.append("bench line of the traced run: " + json.dumps({k: bench[k] for k in ("value", "ms_per_step", "steps", "warmup")}))
     for n, c, t, a, mn, mx in rows[:3]:
