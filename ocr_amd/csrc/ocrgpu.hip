@@ -1495,7 +1495,11 @@ __global__ void k_exchange_headers(Dev d, u32 K) {
     for (u32 l = 0; l < d.n_loc; ++l) { u32 c = d.send_cnt[l * 32]; sent += c > d.send_cap ? d.send_cap : c; }
     u32 mine = d.send_cnt[loc * 32]; if (mine > d.send_cap) mine = d.send_cap;
     u64 *h = (u64 *)&d.send[(size_t)loc * d.send_cap + (d.send_cap - 1)];
-    h[0] = mine; h[1] = (u64)(S->r_end - S->r_begin) + sent; h[2] = sent; h[3] = S->q_total > S->q_end ? S->q_total - S->q_end : 0;
+    // (a step that was launched ahead without a poll may have run out of launches before it was done: that counts as "queued",
+    // so that every partition comes back for a settle round)
+    // activity = EDTs fired by this step + records sent + "EDTs are ready here" (a partition that caught up late, outside the
+    // step its headers describe, still keeps the loop going through what it left ready)
+    h[0] = mine; h[1] = (u64)(S->r_end - S->r_begin) + sent + (S->r_total > S->r_end ? 1u : 0u); h[2] = sent; h[3] = (S->q_total > S->q_end ? S->q_total - S->q_end : 0) + (S->done ? 0u : 1u);
 }
 // the receive side of the equal-split exchange, counts taken from the headers on the device (no host read in between):
 // region s of `recs` (stride records, header in the last slot) carries hdr[0] records from partition s
@@ -1731,6 +1735,26 @@ __global__ void k_reclaim_finish(Dev d, ReclDev rc, u32 compact_log) {
     if (compact_log) c->log_tail = rc.cnt[RC_LOG_KEPT];
 }
 
+// What the host polls, written by ONE small kernel straight into the pinned page it reads (host-coherent memory mapped into
+// the device: the stores are visible when the stream synchronises).  Each hipMemcpyAsync of a few bytes costs a copy packet
+// with its own barrier and completion signal (~10 us on the stream); a level of the stepping loops used three to five.
+#define RP_STATE 1u    // pin[0..31]          = Ctrl.state[K & 1]
+#define RP_SENDCNT 2u  // pin[32 + 32 * loc]  = send counter of partition loc
+#define RP_ERR 4u      // pin[PIN_ERR..+8)    = Ctrl.err[]
+#define RP_QUEUE 8u    // pin[33008], [33009] = Ctrl.q_begin, q_tail
+#define RP_REND 16u    // pin[33010], [33011] = Ctrl.r_end, r_tail
+#define RP_XSUM 32u    // pin[33040..+8)      = the four header sums of the exchange (u64 each)
+__global__ void k_report(Dev d, u32 K, u32 what, u32 *pin, const u64 *xsum) {
+    const u32 t = threadIdx.x;
+    const Ctrl *c = d.ctrl;
+    if ((what & RP_STATE) && t < 32) pin[t] = reinterpret_cast<const u32 *>(&c->state[K & 1])[t];
+    if ((what & RP_SENDCNT) && d.send_cnt) for (u32 l = t; l < d.n_loc; l += blockDim.x) pin[32 + 32 * l] = d.send_cnt[l * 32];
+    if ((what & RP_ERR) && t < 8) pin[33020 + t] = c->err[t];
+    if ((what & RP_QUEUE) && t == 0) { pin[33008] = c->q_begin; pin[33009] = c->q_tail; }
+    if ((what & RP_REND) && t == 0) { pin[33010] = c->r_end; pin[33011] = c->r_tail; }
+    if ((what & RP_XSUM) && t < 8) pin[33040 + t] = reinterpret_cast<const u32 *>(xsum)[t];
+}
+
 // ---- result readback ------------------------------------------------------------------------------------
 __global__ void k_fill_i32(s32 *p, u64 n, s32 v) { u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 __global__ void k_levels(Dev d, u64 first, u64 n, s32 *level_out) {
@@ -1804,7 +1828,7 @@ struct ocrgpu_engine {
     Snapshot snap;
     hipEvent_t ev0, ev1; bool have_events; u32 step_grid; u32 launch_index; u64 fired_cap; bool defer_drain; u32 *send_cnt_dev;
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
-    u32 *pinned_done; u32 apply_flip; hipEvent_t apply_ev[2];
+    u32 *pinned_done, *pinned_dev; u32 apply_flip; hipEvent_t apply_ev[2]; // the polled page and the device's address of it (k_report)
     DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB: the device tables (the device finds them through Ctrl)
     u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
     // comm-platform over RCCL (ocrgpu_comm_*): communicator of this partition, receive regions, a small device word block
@@ -1989,7 +2013,9 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     h.dbl = e->dbl; h.acq_mode = e->acq_mode;
     if (hipMemcpyAsync(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice, e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "ctrl init failed"); }
     // u32 index: [0,32) the polled State; [32, 32 + 32*1024) send counters of up to 1024 locations; [33000, 34000) small read-backs
-    if (hipHostMalloc((void **)&e->pinned_done, 4 * 34816) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
+    if (hipHostMalloc((void **)&e->pinned_done, 4 * 34816, hipHostMallocMapped) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
+    memset(e->pinned_done, 0, 4 * 34816);
+    if (hipHostGetDevicePointer((void **)&e->pinned_dev, e->pinned_done, 0) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostGetDevicePointer failed"); }
     if (cfg->flags & OCRGPU_F_TIMING) { if (hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess) e->have_events = true; }
     if (hipStreamSynchronize(e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "init sync failed"); }
 #undef TRY
@@ -2092,9 +2118,7 @@ static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool ti
             else if (nanny) k_step<true, false><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false><<<grid, BLK, 0, e->stream>>>(d, K);
         }
         launched += batch;
-        HIPCHK(hipMemcpyAsync(e->pinned_done, &d.ctrl->state[(K - 1) & 1], sizeof(State), hipMemcpyDeviceToHost, e->stream));
-        if (d.send_cnt) HIPCHK(hipMemcpyAsync(e->pinned_done + 32, d.send_cnt, 128 * (size_t)d.n_loc, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipMemcpyAsync(e->pinned_done + PIN_ERR, d.ctrl->err, 32, hipMemcpyDeviceToHost, e->stream));
+        k_report<<<1, 64, 0, e->stream>>>(d, K - 1, RP_STATE | RP_SENDCNT | RP_ERR, e->pinned_dev, nullptr);
         HIPCHK(hipStreamSynchronize(e->stream));
         if (((State *)e->pinned_done)->done) break;
         if (launched >= max_launches) break;
@@ -2129,9 +2153,7 @@ static int check_fault(ocrgpu_engine *e) {
 static int drain_events(ocrgpu_engine *e) {
     if (e->defer_drain) return 0; // distributed stepping: the driver calls ocrgpu_step
     // q_begin, q_tail and err[] sit in different cache lines of Ctrl: three small reads, one sync
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 33008, &e->d.ctrl->q_begin, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 33009, &e->d.ctrl->q_tail, 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->pinned_done + PIN_ERR, e->d.ctrl->err, 32, hipMemcpyDeviceToHost, e->stream));
+    k_report<<<1, 64, 0, e->stream>>>(e->d, 0u, RP_QUEUE | RP_ERR, e->pinned_dev, nullptr);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->pinned_done[33009] > e->pinned_done[33008]) { int r = run_steps(e, 0u, ~0ull, false); if (r) return r; }
     return check_fault(e);
@@ -2543,7 +2565,7 @@ static int pop_ready_args(ocrgpu_engine *e, u64 max_edts, u64 max_deps, u64 *n_e
     if (!n_edts_out || !n_deps_out) FAIL(OCRGPU_EINVAL, "null argument");
     if ((max_edts && (!param0_out || !depc_out || !dep_first_out)) || (max_deps && (!dep_guid_out || !dep_value_out))) FAIL(OCRGPU_EINVAL, "null array");
     if (max_edts > 0xFFFFFFFFull || max_deps > 0xFFFFFFFFull) FAIL(OCRGPU_EINVAL, "capacity above 2^32");
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 33010, &e->d.ctrl->r_end, 4, hipMemcpyDeviceToHost, e->stream));
+    k_report<<<1, 64, 0, e->stream>>>(e->d, 0u, RP_REND, e->pinned_dev, nullptr);
     HIPCHK(hipStreamSynchronize(e->stream));
     *r_end_out = e->pinned_done[33010];
     *n_edts_out = 0; *n_deps_out = 0;
@@ -2797,7 +2819,8 @@ static int xchg_land(ocrgpu_engine *e, u64 *out4) {
     k_exchange_apply_hdr<<<nblk(n), 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, e->recv_buf, e->n_db);
     k_exchange_reset<<<1, 1024, 0, e->stream>>>(d);
     k_exchange_sum_hdr<<<1, 1, 0, e->stream>>>(d.n_loc, d.send_cap, e->recv_buf, e->xsum_dev);
-    HIPCHK(hipMemcpyAsync(e->pinned_done + 33040, e->xsum_dev, 32, hipMemcpyDeviceToHost, e->stream));
+    // the header sums, the state the last step ended in and the error counters ride on the same synchronisation (step_ahead does not poll)
+    k_report<<<1, 64, 0, e->stream>>>(d, e->launch_index, RP_XSUM | RP_STATE | RP_ERR, e->pinned_dev, e->xsum_dev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     memcpy(out4, e->pinned_done + 33040, 32);
@@ -2844,33 +2867,74 @@ extern "C" int ocrgpu_exchange_local(ocrgpu_engine_t **engines, u32 n, u64 *acti
 // another partition never sends one on (no event -> remote waiter chains): one exchange per level is then enough.
 // One group = the engines of this process (1 with RCCL; several in the lockstep tests).
 static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
-static int group_round(ocrgpu_engine **g, u32 n, bool rccl, u32 fire, u32 step_flags, u64 *h, double *tm) {
+// ocrgpu_step without its poll: the launches a step normally needs are queued ahead (pending records, the level, what the
+// level's events fire, the launch that notices the end), then the headers; whether the step was really over is read back with
+// the exchange's own synchronisation (xchg_land), so a level costs ONE host synchronisation.  A step that was not over says
+// so in its headers ("queued"), which brings every partition back for a settle round, and is finished with polls there.
+static int step_ahead(ocrgpu_engine *e, u32 fire, u32 flags, u32 n_launch) {
+    ENTER(e);
+    Dev &d = e->d;
+    int r = seal(e); if (r) return r;
+    if (!d.send_cnt || d.n_loc > 1024 || d.send_cap < 2) FAIL(OCRGPU_EINVAL, "exchange not configured");
+    if (e->launch_index > 0xFFFF0000u) e->launch_index = 8;
+    u32 K = e->launch_index + 1;
+    k_begin<<<1, 1, 0, e->stream>>>(d, K, fire, flags & (OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_DROP_EMPTY_LEVEL));
+    const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
+    const u32 grid = e->step_grid > MAX_GRID ? MAX_GRID : (e->step_grid ? e->step_grid : 256u);
+    for (u32 k = 0; k < n_launch; ++k, ++K) {
+        if (e->dbl) { if (nanny) k_step<true, true><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, true><<<grid, BLK, 0, e->stream>>>(d, K); }
+        else if (nanny) k_step<true, false><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false><<<grid, BLK, 0, e->stream>>>(d, K);
+    }
+    e->launches_total += n_launch; e->launch_index = K - 1;
+    k_end<<<1, 1, 0, e->stream>>>(d, K - 1);
+    if (d.n_loc <= 1) { k_owed_bodies<<<grid, BLK, 0, e->stream>>>(d); k_owed_clear<<<1, 1, 0, e->stream>>>(d); } // (with partitions bodies run before the fan-out: nothing is owed)
+    k_exchange_headers<<<1, 1024, 0, e->stream>>>(d, e->launch_index);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int group_round(ocrgpu_engine **g, u32 n, bool rccl, u32 fire, u32 step_flags, u64 *h, double *tm, int *fault) {
     const double t0 = now_s();
-    for (u32 i = 0; i < n; ++i) { int r = ocrgpu_step(g[i], fire, step_flags, nullptr, nullptr, nullptr); if (r && r != OCRGPU_EFAULT) return r; }
+    const bool polled = getenv("OCRGPU_RX_POLLED") != nullptr; // the two-synchronisation round of before (A/B, debugging)
+    for (u32 i = 0; i < n; ++i) {
+        const char *nl = getenv("OCRGPU_RX_LAUNCHES"); // tests: a budget of 1 makes every step run out and take the catch-up path
+        int r = polled ? ocrgpu_step(g[i], fire, step_flags, nullptr, nullptr, nullptr) : step_ahead(g[i], fire, step_flags, nl ? (u32)atoi(nl) : (fire ? 4u : 2u));
+        if (r == OCRGPU_EFAULT) *fault = r; else if (r) return r;
+    }
     const double t1 = now_s();
     u64 rin = 0;
     int r = rccl ? ocrgpu_exchange(g[0], &rin, &h[1], &h[2], &h[3]) : ocrgpu_exchange_local(g, n, &h[1], &h[2], &h[3]);
+    if (r) return r;
+    for (u32 i = 0; i < n; ++i) {
+        if (check_fault(g[i]) == OCRGPU_EFAULT) *fault = OCRGPU_EFAULT;
+        const State *S = (const State *)g[i]->pinned_done;
+        if (polled || S->done) continue;
+        // ran out of launches: finish the step with polls (its fire budget is what the state says is left); what it sends now
+        // goes out with the settle round its "queued" header has already asked everybody for
+        r = ocrgpu_step(g[i], S->allow_fire, step_flags & OCRGPU_STEP_FORCE_LEVEL & (S->allow_fire ? ~0u : 0u), nullptr, nullptr, nullptr);
+        if (r == OCRGPU_EFAULT) *fault = r; else if (r) return r;
+    }
     if (tm) { tm[0] += t1 - t0; tm[1] += now_s() - t1; }
-    return r;
+    return 0;
 }
 static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags, u64 *levels_out) {
     u64 h[4] = {0, 0, 0, 0}, levels = 0;
     double tm[2] = {0, 0}; const bool timing = getenv("OCRGPU_DIST_TIMING") != nullptr;
-    int r;
-    do { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, nullptr))) return r; } while (h[2] || h[3]); // what the main program sent settles first
+    int r, fault = 0;
+    do { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, nullptr, &fault))) return r; } while (h[2] || h[3]); // what the main program sent settles first
     for (;;) {
-        if ((r = group_round(g, n, rccl, 1u, OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr))) return r;
-        const u64 act = h[1];
+        if ((r = group_round(g, n, rccl, 1u, OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault))) return r;
+        u64 act = h[1];
         if (!(flags & OCRGPU_RX_NO_CASCADE) || h[3])
-            while (h[2] || h[3]) { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr))) return r; }
+            while (h[2] || h[3]) { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault))) return r; act += h[1]; }
         if (act == 0) break; // nobody fired or sent anything: the probe level is dropped below
         ++levels;
     }
-    for (u32 i = 0; i < n; ++i) { r = ocrgpu_step(g[i], 0u, OCRGPU_STEP_DROP_EMPTY_LEVEL, nullptr, nullptr, nullptr); if (r && r != OCRGPU_EFAULT) return r; }
+    for (u32 i = 0; i < n; ++i) { r = ocrgpu_step(g[i], 0u, OCRGPU_STEP_DROP_EMPTY_LEVEL, nullptr, nullptr, nullptr); if (r == OCRGPU_EFAULT) fault = r; else if (r) return r; }
     if (timing && g[0]->cfg.location == 0 && levels)
         fprintf(stderr, "[ocrgpu dist timing] us per level: engine step %.1f | exchange (headers, all-to-all, apply, one sync) %.1f | %llu levels\n",
                 1e6 * tm[0] / (double)(levels + 1), 1e6 * tm[1] / (double)(levels + 1), (unsigned long long)levels);
     if (levels_out) *levels_out = levels;
+    if (fault) FAIL(OCRGPU_EFAULT, "the device flagged user-level errors during the run (ocrgpu_get_stats: err[]); the run completed");
     return 0;
 }
 extern "C" int ocrgpu_resolve_exchange(ocrgpu_engine_t *e, u32 flags, u64 *levels_out) {

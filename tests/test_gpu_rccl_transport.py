@@ -60,6 +60,27 @@ def test_c_loop_is_partition_invariant(name, world):
     assert res.diff(O.run_restatement(s)) == []
 
 
+@pytest.mark.parametrize("mode", ["budget1", "polled"])
+@pytest.mark.parametrize("name", ["layered_1k", "event_chain", "counted_events", "channel_events", "cholesky_T8", "wide_fanin"])
+def test_c_loop_step_that_runs_out_of_launches(name, mode, monkeypatch):
+    """A level's launches are queued ahead without a poll (one synchronisation per level); a step that needs more launches than
+    were queued says so in its headers, every partition comes back for a settle round, and the step is finished with polls.
+    With a budget of ONE launch every step takes that path.  "polled": the two-synchronisation round, for comparison."""
+    if mode == "budget1":
+        monkeypatch.setenv("OCRGPU_RX_LAUNCHES", "1")
+    else:
+        monkeypatch.setenv("OCRGPU_RX_POLLED", "1")
+    s = ALL[name]
+    parts = D.build_lockstep([D.Partition(s, r, 3) for r in range(3)])
+    D.resolve_lockstep_c(parts)
+    res = D.gather_result_lockstep(s, parts)
+    errs = [list(p.eng.stats().err) for p in parts]
+    for p in parts:
+        p.eng.close()
+    assert all(sum(e) == 0 for e in errs), errs
+    assert res.diff(O.run_restatement(s)) == []
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_c_loop_one_exchange_per_level(world):
     """the bench's partition-local layered DAG keeps its latch and sink on one rank and has no event -> remote waiter chains
