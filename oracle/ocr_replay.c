@@ -48,6 +48,7 @@ static struct {
     uint64_t *slot_base;     /* [n_edt+1] */
     uint64_t *slot_src;      /* [sum depc] source ref of each EDT pre-slot (0 = none/NULL/DB) */
     uint32_t *feed_ptr, *feed_idx; /* CSR: events feeding event x through ocrAddDependence(evt,evt) */
+    uint32_t *feed_gen;      /* ... and, when the feeder is a CHANNEL, the generation this registration waits for */
     volatile long long *clk; /* [n_evt_total] */
     /* CHANNEL events pair their k-th satisfy with their k-th waiter (hc-event.c:2081-2156): one clock per generation */
     long long **chan_clk; volatile uint32_t *chan_nsat; uint32_t *chan_nreg; uint32_t *slot_gen; /* slot_gen[pre-slot] = generation it waits for */
@@ -96,11 +97,35 @@ static void clk_note(uint32_t x, long long lvl) {
         __sync_bool_compare_and_swap(p, CLK_UNSET, lvl);
     }
 }
+static long long clk_resolve(uint32_t x);
+/* Clock of generation g of CHANNEL x = the (g+1)-th satisfy it has seen.  Its satisfies are the direct ones (noted in chan_clk
+ * as they are made) and the firings of the events registered on it (ocrAddDependence(evt, channel): their clocks resolve like
+ * any event's).  A well-formed stream orders a channel's satisfies causally, and along a causal chain the clock never
+ * decreases, so generation g carries the (g+1)-th smallest clock -- whichever of two equal clocks "really" came first makes
+ * no difference to the level computed from it.  CLK_UNSET = fewer than g+1 satisfies so far. */
+static long long chan_gen_clk(uint32_t x, uint32_t g) {
+    uint32_t nd = G.chan_nsat[x], nf = G.feed_ptr[x + 1] - G.feed_ptr[x], n = 0;
+    long long small[64], *v = nd + nf <= 64 ? small : malloc(8 * (size_t)(nd + nf));
+    for (uint32_t k = 0; k < nd; ++k) { long long c = G.chan_clk[x][k]; if (c != CLK_UNSET) v[n++] = c; }
+    for (uint32_t k = G.feed_ptr[x]; k < G.feed_ptr[x + 1]; ++k) {
+        uint32_t f = G.feed_idx[k];
+        long long c = evt_kind(f) == OCREVT_CHANNEL ? chan_gen_clk(f, G.feed_gen[k]) : clk_resolve(f);
+        if (c != CLK_UNSET) v[n++] = c;
+    }
+    long long r = CLK_UNSET;
+    if (g < n) {
+        for (uint32_t i = 1; i < n; ++i) { long long c = v[i]; uint32_t j = i; while (j && v[j - 1] > c) { v[j] = v[j - 1]; --j; } v[j] = c; }
+        r = v[g];
+    }
+    if (v != small) free(v);
+    return r;
+}
 static long long clk_resolve(uint32_t x) {
     long long m = G.clk[x];
     if (evt_kind(x) != OCREVT_LATCH && m != CLK_UNSET) return m;
     for (uint32_t k = G.feed_ptr[x]; k < G.feed_ptr[x + 1]; ++k) {
-        long long f = clk_resolve(G.feed_idx[k]);
+        uint32_t src = G.feed_idx[k];
+        long long f = evt_kind(src) == OCREVT_CHANNEL ? chan_gen_clk(src, G.feed_gen[k]) : clk_resolve(src);
         if (f > m) m = f;
     }
     return m;
@@ -149,7 +174,7 @@ static ocrGuid_t bodyEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) 
         uint64_t s = G.slot_src[G.slot_base[id] + i];
         uint32_t c = OCRREF_CLS(s);
         if (c == OCRREF_EVT || c == OCRREF_OUTEVT) {
-            long long f = evt_kind(evt_index(s)) == OCREVT_CHANNEL ? G.chan_clk[evt_index(s)][G.slot_gen[G.slot_base[id] + i]]
+            long long f = evt_kind(evt_index(s)) == OCREVT_CHANNEL ? chan_gen_clk(evt_index(s), G.slot_gen[G.slot_base[id] + i])
                                                                   : clk_resolve(evt_index(s));
             if (f == CLK_UNSET) { fprintf(stderr, "replay: EDT %u slot %u fired before its source\n", id, i); abort(); }
             if (f + 1 > lvl) lvl = f + 1;
@@ -323,35 +348,41 @@ static void load_stream(const char *path) {
     }
     /* static pre-pass over main: pre-slot sources and event->event feeders (CSR by destination) */
     uint32_t *cursor = NULL;
+    uint32_t *op_gen = calloc(G.hdr.n_main + 1, 4); /* registration k of a CHANNEL waits for its generation k: program order over ALL its waiters */
     for (int pass = 0; pass < 2; ++pass) {
         for (uint32_t k = 0; k < G.hdr.n_main; ++k) {
             const ocrops_op_t *op = &G.main_ops[k];
             if (op->op != OCROP_ADD_DEP) continue;
             uint32_t sc = OCRREF_CLS(op->a), dc = OCRREF_CLS(op->b);
             int src_evt = (sc == OCRREF_EVT || sc == OCRREF_OUTEVT);
-            if (src_evt && evt_kind(evt_index(op->a)) == OCREVT_CHANNEL && dc != OCRREF_EDT) { fprintf(stderr, "replay: CHANNEL -> event dependences have no clock here\n"); abort(); }
+            const int src_chan = src_evt && evt_kind(evt_index(op->a)) == OCREVT_CHANNEL;
+            if (!pass && src_chan && (dc == OCRREF_EDT || dc == OCRREF_EVT || dc == OCRREF_OUTEVT)) op_gen[k] = G.chan_nreg[evt_index(op->a)]++;
             if (dc == OCRREF_EDT) {
                 if (!pass) {
                     G.slot_src[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = op->a; G.n_sat_edges++;
                     G.slot_mode[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = op->mode;
-                    if (src_evt && evt_kind(evt_index(op->a)) == OCREVT_CHANNEL)
-                        G.slot_gen[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = G.chan_nreg[evt_index(op->a)]++;
+                    if (src_chan) G.slot_gen[G.slot_base[OCRREF_IDX(op->b)] + op->slot] = op_gen[k];
                 }
             } else if (src_evt && (dc == OCRREF_EVT || dc == OCRREF_OUTEVT)) {
                 uint32_t x = evt_index(op->b);
-                if (evt_kind(x) == OCREVT_CHANNEL) { fprintf(stderr, "replay: event -> CHANNEL dependences have no clock here\n"); abort(); }
                 if (!pass && evt_kind(x) == OCREVT_LATCH) G.n_sat_edges++;
-                if (!pass) G.feed_ptr[x + 1]++; else G.feed_idx[cursor[x]++] = evt_index(op->a);
+                if (!pass) G.feed_ptr[x + 1]++;
+                else { /* a CHANNEL feeder: this registration is the channel's next one in program order, EDT pre-slots included */
+                    const uint32_t src = evt_index(op->a);
+                    G.feed_gen[cursor[x]] = op_gen[k];
+                    G.feed_idx[cursor[x]++] = src;
+                }
             }
         }
         if (!pass) {
             for (uint32_t x = 0; x < G.n_evt_total; ++x) G.feed_ptr[x + 1] += G.feed_ptr[x];
             G.feed_idx = calloc(G.feed_ptr[G.n_evt_total] + 1, 4);
+            G.feed_gen = calloc(G.feed_ptr[G.n_evt_total] + 1, 4);
             cursor = malloc(4 * (G.n_evt_total + 1));
             memcpy(cursor, G.feed_ptr, 4 * (G.n_evt_total + 1));
         }
     }
-    free(cursor);
+    free(cursor); free(op_gen);
     for (uint32_t k = 0; k < G.hdr.n_script; ++k)
         if (G.script[k].op == OCROP_SATISFY && evt_kind(evt_index(G.script[k].a)) == OCREVT_LATCH) G.n_sat_edges++;
 }

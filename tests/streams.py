@@ -348,7 +348,44 @@ def channel_events():
     return b.finish([a, bb, c, drv], start)
 
 
-SEMANTIC = [counted_after_null_preslot, channel_events, latch_decr_then_incr, latch_incr2_decr2, latch_init_counter, once_no_waiters, sticky_early_and_late,
+def channel_event_deps():
+    """CHANNEL events as source AND destination of event dependences (hc-event.c:2081-2156 with an event as the waiter /
+    commonSatisfyWaiters reaching a channel): a STICKY's firing is generation 0 of a channel; the channel's registrations --
+    in program order: a ONCE event, a LATCH's DECR slot, an EDT pre-slot, a second channel -- each take one generation."""
+    b = Builder("channel_event_deps")
+    start = b.evt(EVT_ONCE)
+    d0, d1 = b.db(900), b.db(901)
+    ch = b.evt(EVT_CHANNEL, 8)
+    st = b.evt(EVT_STICKY)
+    b.add_dep(st, ch, 0)                         # the sticky's satisfy becomes generation 0 of the channel
+    once = b.evt(EVT_ONCE)
+    lt = b.evt(EVT_LATCH, 1)
+    ch2 = b.evt(EVT_CHANNEL, 2)
+    b.add_dep(ch, once, 0)                       # registration 0: generation 0 -> ONCE event -> EDT a
+    b.add_dep(ch, lt, LATCH_DECR)                # registration 1: generation 1 -> latch DECR -> EDT c
+    a = b.edt(2, BODY_HASH)
+    b.add_dep(start, a, 0)
+    b.add_dep(once, a, 1)
+    c = b.edt(2, BODY_NOP)
+    b.add_dep(start, c, 0)
+    b.add_dep(lt, c, 1)
+    e = b.edt(2, BODY_HASH)
+    b.add_dep(start, e, 0)
+    b.add_dep(ch, e, 1)                          # registration 2: generation 2 -> EDT e's pre-slot
+    b.add_dep(ch, ch2, 0)                        # registration 3: generation 3 -> generation 0 of the second channel
+    f = b.edt(2, BODY_HASH)
+    b.add_dep(start, f, 0)
+    b.add_dep(ch2, f, 1)
+    drv = b.edt(1, BODY_NOP)
+    b.add_dep(start, drv, 0)
+    b.script_satisfy(drv, st, d0)                # level 0: sticky fires -> generation 0 -> once -> a at level 1
+    b.script_satisfy(a, ch, 0)                   # level 1: generation 1 -> latch -> c at level 2
+    b.script_satisfy(c, ch, d1)                  # level 2: generation 2 -> e at level 3 (with d1)
+    b.script_satisfy(e, ch, b.outdb(e))          # level 3: generation 3 -> ch2 generation 0 -> f at level 4
+    return b.finish([a, c, e, f, drv], start)
+
+
+SEMANTIC = [channel_event_deps, counted_after_null_preslot, channel_events, latch_decr_then_incr, latch_incr2_decr2, latch_init_counter, once_no_waiters, sticky_early_and_late,
             counted_events, idem_double_satisfy, mode_null_forces_null, db_and_null_sources, event_chain, forward_and_nop,
             destroy_and_unfired, wide_fanin]
 

@@ -113,36 +113,19 @@ def test_lazy_frontier_counted_event():
 
 def test_channel_to_event_and_event_to_channel():
     """CHANNEL events as source AND destination of event dependences (a STICKY feeding a channel; a channel feeding a
-    latch and a ONCE event).  Parity UNPINNED for these two shapes: the reference runs them, but the replay harness
-    has no clock for them (oracle/ocr_replay.c aborts), so the engine is held to the CPU restatement only."""
-    from ocr_amd.opstream import (BODY_HASH, BODY_NOP, EVT_CHANNEL, EVT_LATCH, EVT_ONCE, EVT_STICKY, LATCH_DECR, MODE_RO,
-                                  Builder)
-    b = Builder("channel_event_deps")
-    start = b.evt(EVT_ONCE)
-    d0 = b.db(900)
-    ch = b.evt(EVT_CHANNEL, 4)
-    st = b.evt(EVT_STICKY)
-    b.add_dep(st, ch, 0)                         # the sticky's satisfy becomes generation 0 of the channel
-    once = b.evt(EVT_ONCE)
-    lt = b.evt(EVT_LATCH, 1)
-    b.add_dep(ch, once, 0)                       # generation 0 -> ONCE event -> EDT a
-    b.add_dep(ch, lt, LATCH_DECR)                # generation 1 -> latch DECR -> EDT c
-    a = b.edt(2, BODY_HASH)
-    b.add_dep(start, a, 0)
-    b.add_dep(once, a, 1)
-    c = b.edt(2, BODY_NOP)
-    b.add_dep(start, c, 0)
-    b.add_dep(lt, c, 1)
-    drv = b.edt(1, BODY_NOP)
-    b.add_dep(start, drv, 0)
-    b.script_satisfy(drv, st, d0)                # level 0: sticky fires -> channel generation 0 -> once -> a at level 1
-    b.script_satisfy(a, ch, 0)                   # level 1: generation 1 -> latch -> c at level 2
-    s = b.finish([a, c, drv], start)
+    ONCE event, a latch, an EDT pre-slot and another channel).  Pinned since round 2: the replay harness clocks a channel's
+    generations whatever satisfies them and whoever waits for them (oracle/ocr_replay.c: chan_gen_clk), and
+    tests/golden/channel_event_deps.res is what the reference runtime did (1 and 4 workers)."""
+    import os
+    import streams
+    from ocr_amd.opstream import Result
+    s = streams.channel_event_deps()
+    gold = Result.from_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "channel_event_deps.res"))
     ref = O.run_restatement(s)
-    assert list(ref.level[:3]) == [1, 2, 0]
+    assert list(ref.level[:5]) == [1, 2, 3, 4, 0] and ref.diff(gold) == []
     for flags in (engine.F_NANNY, 0):
         r, stt = engine.run_stream(s, flags=flags)
-        assert sum(stt.err) == 0 and r.diff(ref) == []
+        assert sum(stt.err) == 0 and r.diff(ref) == [] and r.diff(gold) == []
     for world in (2, 3):
         parts = D.build_lockstep([D.Partition(s, r, world) for r in range(world)])
         D.resolve_lockstep(parts)
