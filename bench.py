@@ -72,7 +72,7 @@ def main():
     seed = opstream.SEED_BASE + 2 + 1000 * rank
     s = opstream.layered_dag(args.n_edt, args.width, seed=seed)
     start_op = s.main[-1:]                      # the final ocrEventSatisfy(start)
-    built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
+    built = s.with_main(s.main[:-1])
     t0 = time.time()
     prog = engine.StreamProgram(built, device=local, flags=engine.F_TIMING).build()
     eng = prog.eng

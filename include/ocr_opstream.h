@@ -50,8 +50,12 @@ enum {
     OCRBODY_NOP = 0,  /* returns NULL_GUID                                              */
     OCRBODY_HASH = 1, /* folds id + every depv[i] payload into a u64, stores it in a new DB, returns that DB */
     OCRBODY_FWD0 = 2, /* returns depv[0].guid                                           */
-    OCRBODY_HOST = 3  /* GPU engine only: the body is host code; the EDT is handed out by ocrgpu_pop_ready and its
+    OCRBODY_HOST = 3, /* GPU engine only: the body is host code; the EDT is handed out by ocrgpu_pop_ready and its
                          epilogue (output-event satisfy) comes back through ocrgpu_event_satisfy_slot */
+    OCRBODY_TILE = 4  /* streams with tile datablocks (hdr.db_words == 64): the pre-slots that carry a datablock carry 1..3
+                         tiles; the LAST of them is updated IN PLACE, C -= X * Y^T over wrapping 64-bit integers (X = the first
+                         input tile, or C itself when there is none; Y = the second input, or X), and its guid is returned.
+                         val = checksum of the updated tile.  (8x8 int64 tiles, integer recurrences) */
 };
 #define OCRBODY_KIND(b) ((b) & 0xFF)
 #define OCRBODY_F_OUTEVT 0x100u /* created with an output event (ONCE, hc-task.c:955)  */
@@ -68,7 +72,9 @@ enum { OCRMODE_NULL = 0, OCRMODE_CONST = 1, OCRMODE_RW = 2, OCRMODE_EW = 4, OCRM
 typedef struct {
     uint64_t magic;
     uint32_t n_edt, n_evt, n_db, n_main, n_script, sink_edt;
-    uint32_t pad[8];
+    uint32_t db_words; /* 0: a datablock is {value, id} (16 bytes).  64: every OCROP_DB_CREATE datablock also carries an 8x8 tile of
+                          64-bit integers behind those two words (528 bytes), word w initialised to ocrops_tile_init(value, w)  */
+    uint32_t pad[7];
 } ocrops_hdr_t; /* 64 B */
 
 typedef struct { uint32_t depc, body, script_begin, script_len; } ocrops_edt_t; /* 16 B */
@@ -81,7 +87,8 @@ typedef struct { uint8_t op, mode; uint16_t pad; uint32_t slot; uint64_t a, b; }
  * level[e]     s32  topological level at which EDT e fired (-1: never fired)
  * val[e]       u64  HASH checksum of EDT e (0 for other bodies / unfired)
  * evt_state[v] u64  v in [0,n_evt) explicit events, n_evt+e = output event of EDT e
- * db_val[d]    u64  d in [0,n_db) created DBs, n_db+e = output DB of EDT e (0 if none)
+ * db_val[d]    u64  d in [0,n_db) created DBs, n_db+e = output DB of EDT e (0 if none);
+ *                   for a tile datablock (hdr.db_words == 64): ocrops_tile_checksum of its final contents
  */
 enum { OCREVS_DESTROYED = 0, OCREVS_LIVE_UNSAT = 1, OCREVS_LIVE_SAT = 2, OCREVS_ABSENT = 3 };
 /* evt_state = code | aux<<8 ; aux = (u32)latch counter for a live LATCH,
@@ -109,5 +116,33 @@ OCROPS_HD static inline uint64_t ocrops_mix64(uint64_t z) {
 OCROPS_HD static inline uint64_t ocrops_hash_init(uint64_t edt_id) { return ocrops_mix64(edt_id ^ 0x0C5200000000ULL); }
 OCROPS_HD static inline uint64_t ocrops_hash_step(uint64_t v, uint32_t slot, uint64_t payload_val, uint64_t dbid_plus1) {
     return ocrops_mix64(v ^ (payload_val + dbid_plus1 * OCROPS_HASH_K + slot));
+}
+/* TILE bodies: 8x8 tiles of wrapping 64-bit integers, row-major.  Every executor uses these definitions; the element form
+ * (ocrops_tile_elem) is what a GPU lane computes, the whole-tile form is for the CPU executors. */
+#define OCROPS_TILE_N 8u
+#define OCROPS_TILE_WORDS 64u
+OCROPS_HD static inline uint64_t ocrops_tile_init(uint64_t value, uint32_t w) { return ocrops_mix64(value + w); }
+/* element (r, c) of C - X * Y^T, all operands read BEFORE anything is written (X and Y may alias C) */
+OCROPS_HD static inline uint64_t ocrops_tile_elem(const uint64_t *C, const uint64_t *X, const uint64_t *Y, uint32_t r, uint32_t c) {
+    uint64_t acc = C[r * OCROPS_TILE_N + c];
+    for (uint32_t t = 0; t < OCROPS_TILE_N; ++t) acc -= X[r * OCROPS_TILE_N + t] * Y[c * OCROPS_TILE_N + t];
+    return acc;
+}
+/* checksum = wrapping sum of the terms (order-free, so a wave can reduce it) */
+OCROPS_HD static inline uint64_t ocrops_tile_term(uint64_t word, uint32_t w) { return ocrops_mix64(word + (uint64_t)w * OCROPS_HASH_K); }
+OCROPS_HD static inline uint64_t ocrops_tile_checksum(const uint64_t *C) {
+    uint64_t s = 0;
+    for (uint32_t w = 0; w < OCROPS_TILE_WORDS; ++w) s += ocrops_tile_term(C[w], w);
+    return s;
+}
+/* C -= X * Y^T in place (X = NULL: X = C; Y = NULL: Y = X); returns the checksum of the result */
+OCROPS_HD static inline uint64_t ocrops_tile_update(uint64_t *C, const uint64_t *X, const uint64_t *Y) {
+    uint64_t out[OCROPS_TILE_WORDS];
+    if (!X) X = C;
+    if (!Y) Y = X;
+    for (uint32_t r = 0; r < OCROPS_TILE_N; ++r)
+        for (uint32_t c = 0; c < OCROPS_TILE_N; ++c) out[r * OCROPS_TILE_N + c] = ocrops_tile_elem(C, X, Y, r, c);
+    for (uint32_t w = 0; w < OCROPS_TILE_WORDS; ++w) C[w] = out[w];
+    return ocrops_tile_checksum(C);
 }
 #endif

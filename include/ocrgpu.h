@@ -83,6 +83,10 @@ typedef struct {
  * list is dealt over, default 256), OCRGPU_STEP_GRID (grid of a step launch, default 2048). */
 #define OCRGPU_F_NANNY 1u  /* detect double satisfy of an EDT pre-slot (hc-task.c:1243); +1 atomic per edge */
 #define OCRGPU_F_TIMING 2u /* bracket resolve's kernels with HIP events on the engine stream   */
+#define OCRGPU_F_WIDE_DB 16u /* every ocrgpu_db_create datablock also carries an 8x8 tile of 64-bit integers (512 bytes, word w =
+                              * ocrops_tile_init(value, w)) that OCRBODY_TILE bodies update in place -- the payload SURVEY.md s8d.3 names
+                              * for the tiled Cholesky (regular-datablock.c:55-215: a datablock is its guid + a buffer the EDT writes).
+                              * ocrgpu_read_dbs reports ocrops_tile_checksum of the tile.  One partition only.                        */
 #define OCRGPU_F_LOCKABLE_DB 8u /* the cfg's datablockfactory=Lockable instead of Regular: an EDT whose pre-slots are all
                                  * satisfied first acquires its datablocks, in ascending guid order, each once, in the mode
                                  * its ocrAddDependence named (DB_MODE_CONST / RW / EW / RO), waits in line on a busy one

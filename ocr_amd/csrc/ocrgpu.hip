@@ -129,7 +129,8 @@ struct alignas(128) Ctrl {
     u32 err[8];
     DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB only (else null): lock word + waiter lists per datablock; access mode per
                                           // EDT pre-slot.  Kept here, not in Dev: the hot kernel's argument block stays as small as it was
-    u32 pad5[20];
+    u64 *tiles;                 // OCRGPU_F_WIDE_DB only (else null): the 8x8 tile of 64-bit integers behind datablock i at tiles[64 * i]
+    u32 pad5[18];
     // during a run
     State state[2];
     Cnt cnt_r[3], cnt_q[3];     // launch K appends through cnt_*[K%3]; launch K+1 reads them; launch K zeroes [(K+1)%3]
@@ -776,27 +777,98 @@ __device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, 
     d.edt[e].val = v; // == the output DB's value (a live DB only for HASH bodies)
 }
 
-// Bodies left over by the previous launch (State.b_begin..b_end): helper workgroup h of nh walks the range.  The EDT
-// lines are read again -- off the critical path, by workgroups that would otherwise have left at once.
+// OCRBODY_TILE (8x8 int64 tiles updated in place by integer recurrences): the pre-slots that carry a datablock
+// name 1..3 tiles; the last is updated, C -= X * Y^T.  tile_operands picks them from the pre-slot words (t[k] = index + 1, 0 = none).
+__device__ __forceinline__ void tile_operands(const u32 *pw, u32 depc, u32 (&t)[3]) {
+    t[0] = t[1] = t[2] = 0;
+#pragma unroll
+    for (u32 k = 0; k < INLINE_SLOTS; ++k) {
+        const u32 p = k < depc ? pw[k] : 0u;
+        if (p) { if (!t[0]) t[0] = p; else if (!t[1]) t[1] = p; else if (!t[2]) t[2] = p; }
+    }
+}
+__device__ __forceinline__ u32 tile_target(const u32 (&t)[3]) { return t[2] ? t[2] : t[1] ? t[1] : t[0]; }
+// A wave runs the TILE bodies of its lanes eight at a time: lanes 8g..8g+7 take the g-th pending body, lane r of the group
+// computes row r of the tile -- its rows of C and X (one 64-byte sector each) and all of Y (eight sectors every lane of the
+// group reads alike), 64 multiply-subtracts, one 64-byte store; the checksum is reduced over the group's eight lanes.
+// (One body at a time with a lane per element made every body wait for its own loads: 64 dependent round trips per wave,
+// 30.7 ms per resolve of the T = 256 Cholesky; eight at a time: see DESIGN.md s7.)  Every lane's operand loads are consumed
+// before the store of any lane is issued (one instruction stream), so operands that alias the target (potrf: C -= C * C^T)
+// are read whole.  Called in wave-uniform control flow.
+__device__ void tile_bodies_wave(const Dev &d, bool has, u32 e, const u32 (&t)[3]) {
+    u64 m = __ballot(has);
+    if (!m) return;
+    u64 *const tiles = d.ctrl->tiles;
+    const u32 lane = lane_id(), g = lane >> 3, r = lane & 7u;
+    while (m) {
+        int src = -1; // the g-th lowest pending lane
+        { u64 mm = m; for (u32 k = 0; k <= g && mm; ++k) { if (k == g) src = __ffsll((long long)mm) - 1; mm &= mm - 1; } }
+        for (int k = 0; k < 8 && m; ++k) m &= m - 1;
+        const int from = src < 0 ? 0 : src;
+        const u32 ee = __shfl(e, from), a = __shfl(t[0], from), b = __shfl(t[1], from), cc = __shfl(t[2], from);
+        if (src < 0) continue; // (no wave-wide operation below this line except within the 8-lane group)
+        const u32 tgt = cc ? cc : b ? b : a, xi = b ? a : tgt, yi = cc ? b : xi;
+        u64 sum = 0;
+        if (tiles && tgt && tgt - 1 < d.max_db && xi - 1 < d.max_db && yi - 1 < d.max_db) {
+            ulonglong2 *Crow = reinterpret_cast<ulonglong2 *>(tiles + 64 * (size_t)(tgt - 1) + 8 * r);
+            const ulonglong2 *Xrow = reinterpret_cast<const ulonglong2 *>(tiles + 64 * (size_t)(xi - 1) + 8 * r);
+            const ulonglong2 *Y = reinterpret_cast<const ulonglong2 *>(tiles + 64 * (size_t)(yi - 1));
+            u64 acc[8], x[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const ulonglong2 cv = Crow[q], xv = Xrow[q]; acc[2 * q] = cv.x; acc[2 * q + 1] = cv.y; x[2 * q] = xv.x; x[2 * q + 1] = xv.y; }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const ulonglong2 yv = Y[4 * c + q]; acc[c] -= x[2 * q] * yv.x + x[2 * q + 1] * yv.y; }
+            }
+            // (all of the group's -- and the wave's -- loads above have returned before the first store below is issued)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Crow[q] = make_ulonglong2(acc[2 * q], acc[2 * q + 1]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sum += ocrops_tile_term(acc[c], 8 * r + c);
+        } else if (tgt && r == 0) atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); // a TILE body on something that is not a tile datablock
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+        if (r == 0) d.edt[ee].val = sum;
+    }
+}
+
+// the per-lane part of a deferred body: the EDT's line, its pre-slot words, and (unless it is a TILE body, which the whole wave
+// runs afterwards) the gathers and the fold
+template <bool TILES>
+__device__ __forceinline__ void deferred_body(const Dev &d, u32 e, bool &tile, u32 (&tt)[3]) {
+    const EdtLine L = d.edt[e];
+    if (OCRBODY_KIND(L.body) == OCRBODY_HOST) return;
+    const u32 *sl; u32 pw[8]; ulonglong2 gb[8];
+    if (L.depc <= INLINE_SLOTS) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pw[k] = L.slot[k] & 0x7FFFFFFFu;
+        pw[6] = pw[7] = 0; sl = d.edt[e].slot;
+    } else {
+        sl = d.slots + L.slot[0];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pw[k] = (u32)k < L.depc ? (sl[k] & 0x7FFFFFFFu) : 0u;
+    }
+    if (TILES && OCRBODY_KIND(L.body) == OCRBODY_TILE) { tile = true; tile_operands(pw, L.depc, tt); return; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
+    run_body(d, e, L.param0, L.depc, sl, gb);
+}
+template <bool TILES>
 __device__ void deferred_bodies(const Dev &d, u32 b_begin, u32 b_end, u32 h, u32 nh) {
-    for (u32 i = b_begin + h * BLK + threadIdx.x; i < b_end; i += nh * BLK) {
-        const u32 e = d.fired[i];
-        if (e == INVALID) continue;
-        const EdtLine L = d.edt[e];
-        if (OCRBODY_KIND(L.body) == OCRBODY_HOST) continue;
-        const u32 *sl; u32 pw[8]; ulonglong2 gb[8];
-        if (L.depc <= INLINE_SLOTS) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) pw[k] = L.slot[k] & 0x7FFFFFFFu;
-            pw[6] = pw[7] = 0; sl = d.edt[e].slot;
-        } else {
-            sl = d.slots + L.slot[0];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) pw[k] = (u32)k < L.depc ? (sl[k] & 0x7FFFFFFFu) : 0u;
+    bool tile = false; u32 tt[3] = {0, 0, 0};
+    if (!TILES) { // every lane for itself
+        for (u32 i = b_begin + h * BLK + threadIdx.x; i < b_end; i += nh * BLK) {
+            const u32 e = d.fired[i];
+            if (e != INVALID) deferred_body<false>(d, e, tile, tt);
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
-        run_body(d, e, L.param0, L.depc, sl, gb);
+        return;
+    }
+    for (u32 base = b_begin + h * BLK; base < b_end; base += nh * BLK) { // workgroup-uniform trip count: tile bodies are wave-wide
+        const u32 i = base + threadIdx.x;
+        const u32 e = i < b_end ? d.fired[i] : INVALID;
+        tile = false;
+        if (e != INVALID) deferred_body<true>(d, e, tile, tt);
+        tile_bodies_wave(d, tile, e, tt);
     }
 }
 
@@ -810,7 +882,9 @@ __device__ void deferred_bodies(const Dev &d, u32 b_begin, u32 b_end, u32 h, u32
 #endif
 
 // One launch = one phase.  K is the launch index (host counter): it selects the state / counter buffers.
-template <bool NANNY, bool LOCKABLE>
+// TILES (OCRGPU_F_WIDE_DB): OCRBODY_TILE bodies are compiled in -- a variant of its own, so that the default kernel keeps
+// its registers (118 VGPRs, 4 waves per SIMD; with the tile code inline: 137 and 3).
+template <bool NANNY, bool LOCKABLE, bool TILES>
 __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #ifdef OCRGPU_STAMPS
     u64 _t0 = __builtin_amdgcn_s_memrealtime();
@@ -883,7 +957,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
         u32 n_help = (P.b_end - P.b_begin + BLK - 1) / BLK;
         if (n_help < HELPERS) n_help = HELPERS;
         if (n_help > gridDim.x - part) n_help = gridDim.x - part;
-        if (blockIdx.x >= part && blockIdx.x < part + n_help) deferred_bodies(d, P.b_begin, P.b_end, blockIdx.x - part, n_help);
+        if (blockIdx.x >= part && blockIdx.x < part + n_help) deferred_bodies<TILES>(d, P.b_begin, P.b_end, blockIdx.x - part, n_help);
     }
     if (N.done) return;
     Step S;
@@ -921,7 +995,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (i < S.r_end) e = d.fired[i];
             const bool mine = e != INVALID;
             bool epi = false;
-            u32 body = 0, depc = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr; ulonglong2 gb[8];
+            u32 body = 0, depc = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr; ulonglong2 gb[8]; u32 tt[3] = {0, 0, 0};
             if (mine) {
                 const EdtLine L = d.edt[e]; // the one 64-B read that carries everything this EDT needs to fire
                 body = L.body; depc = L.depc; id = L.param0;
@@ -935,7 +1009,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) pw[k] = (u32)k < depc ? (sl[k] & 0x7FFFFFFFu) : 0u;
                 }
-                if (!defer) {
+                if (!defer && !(TILES && OCRBODY_KIND(body) == OCRBODY_TILE)) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
                 }
@@ -943,10 +1017,11 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                 const u32 kind = OCRBODY_KIND(body);
                 if (kind == OCRBODY_HASH) ret = d.max_db + e + 1;
                 else if (kind == OCRBODY_FWD0) ret = pw[0];
+                else if (TILES && kind == OCRBODY_TILE) { tile_operands(pw, depc, tt); ret = tile_target(tt); } // the tile it updates travels on
                 // With other partitions around, a satisfy may carry this EDT's output DB away by value in this very
                 // launch, so the body runs first; on a single partition it runs after the fan-out (off the critical path).
                 const bool host_body = kind == OCRBODY_HOST; // taskExecute happens on the host (ocrgpu_pop_ready)
-                if (body_first && !host_body) run_body(d, e, id, depc, sl, gb);
+                if (body_first && !host_body && kind != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb); // (tile datablocks: one partition only)
                 if (body & BODY_F_SCRIPT) { // the body's own ocrEventSatisfySlot / ocrEventDestroy calls
                     u32 sb = d.edt_script_begin[e], sn = d.edt_script_len[e];
                     for (u32 k = 0; k < sn; ++k) {
@@ -993,7 +1068,8 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             STAMP(2);
             if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             STAMP(3);
-            if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST) run_body(d, e, id, depc, sl, gb);
+            if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST && OCRBODY_KIND(body) != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb);
+            if (TILES) tile_bodies_wave(d, mine && !defer && OCRBODY_KIND(body) == OCRBODY_TILE, e, tt);
         }
     } else {
         // ---- queued satisfies: API calls, fired chained events, big-row pieces, direct EDT pre-slot satisfies ----
@@ -1037,7 +1113,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
         }
     }
-    if (owed && part == gridDim.x) deferred_bodies(d, P.b_begin, P.b_end, blockIdx.x, gridDim.x); // no idle workgroup in this launch
+    if (owed && part == gridDim.x) deferred_bodies<TILES>(d, P.b_begin, P.b_end, blockIdx.x, gridDim.x); // no idle workgroup in this launch
     STAMP(4);
     // ---- statistics: the counters are wave totals (ballots where they are counted) -> this workgroup's own slot, one
     // fire-and-forget atomic per wave and counter.  No shuffles, no LDS stage and no barrier: a barrier's workgroup fence would make every wave wait here for its fan-out stores to land ----
@@ -1054,7 +1130,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 }
 
 // A run that stopped on its launch budget pays the bodies it owes before the caller can look at values.
-__global__ __launch_bounds__(BLK) void k_owed_bodies(Dev d) { deferred_bodies(d, d.ctrl->b_begin, d.ctrl->b_end, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(BLK) void k_owed_bodies(Dev d) { deferred_bodies<true>(d, d.ctrl->b_begin, d.ctrl->b_end, blockIdx.x, gridDim.x); }
 __global__ void k_owed_clear(Dev d) { d.ctrl->b_begin = d.ctrl->b_end = 0; }
 
 // Start a run at launch index K0: seed state[(K0-1)&1] from the between-runs view (single thread).
@@ -1141,6 +1217,13 @@ __global__ void k_db_create(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n, co
     gtab_put(d, g, (u64)x + 1);
     if (guids_out) guids_out[i] = g;
 }
+// OCRGPU_F_WIDE_DB: the tile behind each datablock the call created (same index rule as k_db_create), one thread per word
+__global__ void k_tile_init(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n, const u64 *value, u32 first_idx) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (i >= n * OCROPS_TILE_WORDS) return;
+    const u64 j = i / OCROPS_TILE_WORDS; const u32 w = (u32)(i % OCROPS_TILE_WORDS);
+    d.ctrl->tiles[(size_t)take_index(rc.free_db, n_free, n_take, first_idx, j) * OCROPS_TILE_WORDS + w] = ocrops_tile_init(value[j], w);
+}
 // overflow slot words an EDT needs (0 when its pre-slots fit the line)
 __global__ void k_ovf_counts(u64 n, const u32 *depc, u32 *ovf) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -1154,7 +1237,7 @@ __global__ void k_edt_create(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n, c
     if (i >= n) return;
     u32 e = take_index(rc.free_edt, n_free, n_take, first_idx, i), dc = depc[i], b = body[i] & 0xFFFFu;
     EdtGuids eg = {0, 0, 0, 0};
-    if (d.ctrl->dbl && dc > LOCKABLE_MAX_DEPC) { // acq_walk / release_all are quadratic in depc: refuse what would not finish (the EDT does not exist)
+    if ((OCRBODY_KIND(b) == OCRBODY_TILE && (dc > INLINE_SLOTS || !d.ctrl->tiles)) || (d.ctrl->dbl && dc > LOCKABLE_MAX_DEPC)) { // a TILE body reads its (<= 6) pre-slots from the line, and needs tile datablocks // acq_walk / release_all are quadratic in depc: refuse what would not finish (the EDT does not exist)
         atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); EdtLine Z; memset(&Z, 0, sizeof Z); Z.out_state = (u32)ST_ABSENT; d.edt[e] = Z; rc.edt_guids[e] = eg;
         if (!gin) { guids_out[i] = 0; if (outevt_out) outevt_out[i] = 0; if (outdb_out) outdb_out[i] = 0; }
         return;
@@ -1794,7 +1877,8 @@ __global__ void k_read_dbs(Dev d, u32 first, u64 n, const s32 *level, u32 first_
     if (level) { // output DBs exist once their EDT has fired with a HASH body
         bool live = level[i] >= 0 && OCRBODY_KIND(d.edt[first_edt + i].body) == OCRBODY_HASH;
         out[i] = live ? d.edt[first_edt + i].val : 0;
-    } else out[i] = d.db[first + i].x;
+    } else if (d.ctrl->tiles) out[i] = ocrops_tile_checksum(d.ctrl->tiles + 64 * (size_t)(first + i)); // a tile datablock reports its contents
+    else out[i] = d.db[first + i].x;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1804,11 +1888,13 @@ static thread_local char g_err[512] = "";
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) { snprintf(g_err, sizeof g_err, "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); return OCRGPU_EHIP; } } while (0)
 #define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
 
-struct Snapshot { DbLock *dbl; EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; u64 *chan_wait; u32 *chan_sat; u32 chan_wait_used, chan_sat_used; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries;
+struct Snapshot { u64 *tiles; DbLock *dbl; EdtLine *edt; EvtRec *evt; u64 *counted; ulonglong2 *lazy_tab; u32 *slots; u64 n_slots; u64 *chan_wait; u32 *chan_sat; u32 chan_wait_used, chan_sat_used; u32 *fired; Ctrl *ctrl; u32 n_edt, n_evt, n_db, n_fired_entries;
                   u64 edges_upper, seal_epoch, err_seen, mut_epoch; bool valid; };
 static void snap_free(Snapshot &s) {
     if (s.dbl) (void)hipFree(s.dbl);
     s.dbl = nullptr;
+    if (s.tiles) (void)hipFree(s.tiles);
+    s.tiles = nullptr;
     (void)hipFree(s.edt); (void)hipFree(s.evt); (void)hipFree(s.counted); (void)hipFree(s.lazy_tab); (void)hipFree(s.slots); (void)hipFree(s.chan_wait); (void)hipFree(s.chan_sat); (void)hipFree(s.fired); (void)hipFree(s.ctrl);
     s.valid = false;
 }
@@ -1830,6 +1916,7 @@ struct ocrgpu_engine {
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
     u32 *pinned_done, *pinned_dev; u32 apply_flip; hipEvent_t apply_ev[2]; // the polled page and the device's address of it (k_report)
     DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB: the device tables (the device finds them through Ctrl)
+    u64 *tiles;                           // OCRGPU_F_WIDE_DB: 64 words per explicit datablock (through Ctrl as well)
     u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
     // comm-platform over RCCL (ocrgpu_comm_*): communicator of this partition, receive regions, a small device word block
     void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records; u64 *xsum_dev;
@@ -1940,8 +2027,8 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     memset(&e->rc, 0, sizeof e->rc); e->n_free_edt = e->n_free_evt = e->n_free_db = e->n_held = 0; e->mut_epoch = 0; e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->seal_epoch = 0; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
-    e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->snap.dbl = nullptr; e->have_events = false;
-    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr; e->dbl = nullptr; e->acq_mode = nullptr;
+    e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->snap.dbl = nullptr; e->snap.tiles = nullptr; e->have_events = false;
+    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr; e->dbl = nullptr; e->acq_mode = nullptr; e->tiles = nullptr;
     e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->pop_cursor = e->snap_pop_cursor = 0; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
     { const char *mp = getenv("OCRGPU_SPREAD_WGS"); u32 v = mp ? (u32)atoi(mp) : 256u; d.spread_wgs = v < 1 ? 1u : (v > MAX_GRID ? (u32)MAX_GRID : v); }
@@ -1981,6 +2068,8 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.log_src, 4 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.log_rec, 8 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.db, 16 * (size_t)n_db_total));
+    if ((cfg->flags & OCRGPU_F_WIDE_DB) && (cfg->flags & OCRGPU_F_LOCKABLE_DB)) { ocrgpu_fini(e); FAIL(OCRGPU_EINVAL, "OCRGPU_F_WIDE_DB and OCRGPU_F_LOCKABLE_DB cannot be combined"); }
+    if (cfg->flags & OCRGPU_F_WIDE_DB) TRY(dalloc(e, (void **)&e->tiles, 8 * OCROPS_TILE_WORDS * (size_t)cfg->max_db));
     if (cfg->flags & OCRGPU_F_LOCKABLE_DB) {
         TRY(dalloc(e, (void **)&e->dbl, sizeof(DbLock) * (size_t)n_db_total));
         TRY(dalloc(e, (void **)&e->acq_mode, (size_t)cfg->max_edt * INLINE_SLOTS + (size_t)d.max_slots));
@@ -2010,7 +2099,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&e->rc.cnt, 4 * RC_N));
     // ctrl.level starts at -1 (main-program satisfies are "level -1")
     Ctrl h; memset(&h, 0, sizeof h); h.level = 0xFFFFFFFFu; h.state[0].done = h.state[1].done = 1;
-    h.dbl = e->dbl; h.acq_mode = e->acq_mode;
+    h.dbl = e->dbl; h.acq_mode = e->acq_mode; h.tiles = e->tiles;
     if (hipMemcpyAsync(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice, e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "ctrl init failed"); }
     // u32 index: [0,32) the polled State; [32, 32 + 32*1024) send counters of up to 1024 locations; [33000, 34000) small read-backs
     if (hipHostMalloc((void **)&e->pinned_done, 4 * 34816, hipHostMallocMapped) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
@@ -2101,6 +2190,14 @@ static int seal(ocrgpu_engine *e) {
 // Launch k_step ahead of the device until it reports `done`.  Every poll brings back the whole phase state and
 // (when partitions are configured) the per-destination send counters in ONE synchronisation: pinned[0..31] = State,
 // pinned[32 + 32*loc] = records queued for partition loc.
+// the k_step variant this engine runs (NANNY x Lockable datablocks, or tile datablocks)
+static void launch_step(ocrgpu_engine *e, u32 grid, u32 K) {
+    const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
+    const Dev &d = e->d;
+    if (e->tiles) { if (nanny) k_step<true, false, true><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false, true><<<grid, BLK, 0, e->stream>>>(d, K); }
+    else if (e->dbl) { if (nanny) k_step<true, true, false><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, true, false><<<grid, BLK, 0, e->stream>>>(d, K); }
+    else if (nanny) k_step<true, false, false><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false, false><<<grid, BLK, 0, e->stream>>>(d, K);
+}
 static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool timing, u32 force_level = 0, u32 first_batch = 0) {
     Dev &d = e->d;
     int r = seal(e); if (r) return r;
@@ -2114,8 +2211,7 @@ static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool ti
     if (timing && e->have_events) HIPCHK(hipEventRecord(e->ev0, e->stream));
     for (;;) {
         for (u32 k = 0; k < batch; ++k, ++K) {
-            if (e->dbl) { if (nanny) k_step<true, true><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, true><<<grid, BLK, 0, e->stream>>>(d, K); }
-            else if (nanny) k_step<true, false><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false><<<grid, BLK, 0, e->stream>>>(d, K);
+            launch_step(e, grid, K);
         }
         launched += batch;
         k_report<<<1, 64, 0, e->stream>>>(d, K - 1, RP_STATE | RP_SENDCNT | RP_ERR, e->pinned_dev, nullptr);
@@ -2251,6 +2347,7 @@ extern "C" int ocrgpu_db_create(ocrgpu_engine_t *e, u64 n, const u64 *value, con
     if (given) r = stage_in(e, (const u64 *)guids_out, n, where, &dgin); else r = stage_out_alloc(e, guids_out, n, where, &dg);
     if (r) return r;
     k_db_create<<<nblk(n), 256, 0, e->stream>>>(e->d, e->rc, e->n_free_db, take, n, dv, dt, e->n_db, e->counter, dgin, dg);
+    if (e->tiles) k_tile_init<<<nblk(n * OCROPS_TILE_WORDS), 256, 0, e->stream>>>(e->d, e->rc, e->n_free_db, take, n, dv, e->n_db);
     e->n_db += (u32)(n - take); e->n_free_db -= take; if (take) ++e->mut_epoch; if (!given) e->counter += n;
     if (!given && (r = stage_out_copy(e, guids_out, dg, n, where))) return r;
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
@@ -2630,6 +2727,7 @@ extern "C" int ocrgpu_step_info(ocrgpu_engine_t *e, u64 *out4) {
 extern "C" int ocrgpu_exchange_config(ocrgpu_engine_t *e, u32 n_locations, void *send_dev_buf, u64 records_per_dest, u64 max_remote_dsts) {
     ENTER(e);
     if (e->dbl) FAIL(OCRGPU_EINVAL, "OCRGPU_F_LOCKABLE_DB arbitrates within one partition: not with an exchange configured");
+    if (e->tiles && n_locations > 1) FAIL(OCRGPU_EINVAL, "OCRGPU_F_WIDE_DB: records carry 16-byte datablocks by value; tile datablocks stay within one partition");
     if (n_locations == 0 || n_locations > 1024 || e->cfg.location >= n_locations) FAIL(OCRGPU_EINVAL, "bad n_locations");
     if (n_locations > 1 && (records_per_dest == 0 || records_per_dest > 0xFFFFFFFFull)) FAIL(OCRGPU_EINVAL, "records_per_dest must be in [1, 2^32)");
     Dev &d = e->d;
@@ -2882,8 +2980,7 @@ static int step_ahead(ocrgpu_engine *e, u32 fire, u32 flags, u32 n_launch) {
     const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
     const u32 grid = e->step_grid > MAX_GRID ? MAX_GRID : (e->step_grid ? e->step_grid : 256u);
     for (u32 k = 0; k < n_launch; ++k, ++K) {
-        if (e->dbl) { if (nanny) k_step<true, true><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, true><<<grid, BLK, 0, e->stream>>>(d, K); }
-        else if (nanny) k_step<true, false><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false><<<grid, BLK, 0, e->stream>>>(d, K);
+        launch_step(e, grid, K);
     }
     e->launches_total += n_launch; e->launch_index = K - 1;
     k_end<<<1, 1, 0, e->stream>>>(d, K - 1);
@@ -3010,7 +3107,11 @@ extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     int r = seal(e); if (r) return r;
     Dev &d = e->d; Snapshot &s = e->snap;
     if (s.valid) { HIPCHK(hipStreamSynchronize(e->stream)); snap_free(s); }
-    s.dbl = nullptr;
+    s.dbl = nullptr; s.tiles = nullptr;
+    if (e->tiles && e->n_db) { // tiles are updated in place: they are part of what a re-arm puts back
+        HIPCHK(hipMalloc((void **)&s.tiles, 8 * OCROPS_TILE_WORDS * (size_t)e->n_db));
+        HIPCHK(hipMemcpyAsync(s.tiles, e->tiles, 8 * OCROPS_TILE_WORDS * (size_t)e->n_db, hipMemcpyDeviceToDevice, e->stream));
+    }
     if (e->dbl) {
         HIPCHK(hipMalloc((void **)&s.dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt)));
         HIPCHK(hipMemcpyAsync(s.dbl, e->dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt), hipMemcpyDeviceToDevice, e->stream));
@@ -3058,6 +3159,7 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     e->edges_upper = s.edges_upper; e->err_seen = s.err_seen; // Ctrl.err[] goes back with Ctrl
     if (e->seal_epoch != s.seal_epoch || e->csr_dirty) e->csr_dirty = true;
     if (e->d.send_cnt) k_exchange_reset<<<1, 1024, 0, e->stream>>>(e->d);
+    if (e->tiles && s.tiles) HIPCHK(hipMemcpyAsync(e->tiles, s.tiles, 8 * OCROPS_TILE_WORDS * (size_t)s.n_db, hipMemcpyDeviceToDevice, e->stream));
     if (e->dbl && s.dbl) HIPCHK(hipMemcpyAsync(e->dbl, s.dbl, sizeof(DbLock) * ((size_t)d.max_db + d.max_edt), hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.edt, s.edt, sizeof(EdtLine) * (size_t)e->n_edt, hipMemcpyDeviceToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(d.evt, s.evt, sizeof(EvtRec) * (size_t)e->n_evt, hipMemcpyDeviceToDevice, e->stream));

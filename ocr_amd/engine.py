@@ -21,6 +21,7 @@ from .opstream import OpStream, Result
 HOST, DEVICE = 0, 1
 GUIDS_GIVEN = 4   # OR into `where` of the create calls: guid arrays are inputs (ocrgpu.h)
 F_NANNY, F_TIMING = 1, 2
+F_WIDE_DB = 16     # datablocks carry an 8x8 int64 tile that OCRBODY_TILE bodies update in place
 F_LOCKABLE_DB = 8  # datablocks arbitrate their acquire modes (the cfg's datablockfactory=Lockable)
 EFAULT = -14       # OCRGPU_EFAULT: the device flagged a user-level error during the call (which completed)
 
@@ -443,6 +444,8 @@ class StreamProgram:
         self.db_index = np.full(s.n_db, -1, np.int64)
         n_slots = int(s.edt["depc"].sum())
         n_adddep = int((s.main["op"] == ops.OP_ADD_DEP).sum())
+        if s.db_words == 64:
+            flags |= F_WIDE_DB
         self.eng = engine or Engine(max_edt=max(s.n_edt, 1) + slack, max_evt=max(s.n_evt, 1), max_db=max(s.n_db, 1),
                                     max_slots=n_slots + 1, max_edges=n_adddep + 1 + ops.channel_ring_slots(s), device=device, flags=flags,
                                     tolerate_faults=tolerate_faults)

@@ -17,7 +17,7 @@ RES_MAGIC = 0x0031534552524F43
 
 OP_EVT_CREATE, OP_DB_CREATE, OP_EDT_CREATE, OP_ADD_DEP, OP_SATISFY, OP_EVT_DESTROY = 1, 2, 3, 4, 5, 6
 REF_NULL, REF_EDT, REF_EVT, REF_DB, REF_OUTEVT, REF_OUTDB, REF_DEPV, REF_UNINIT = range(8)
-BODY_NOP, BODY_HASH, BODY_FWD0 = 0, 1, 2
+BODY_NOP, BODY_HASH, BODY_FWD0, BODY_HOST, BODY_TILE = 0, 1, 2, 3, 4
 BODY_F_OUTEVT, BODY_F_SINK = 0x100, 0x200
 EVT_ONCE, EVT_IDEM, EVT_STICKY, EVT_LATCH, EVT_COUNTED, EVT_CHANNEL = 1, 2, 3, 4, 5, 6
 LATCH_DECR, LATCH_INCR = 0, 1
@@ -25,7 +25,7 @@ MODE_NULL, MODE_CONST, MODE_RW, MODE_EW, MODE_RO = 0, 1, 2, 4, 8
 EVS_DESTROYED, EVS_LIVE_UNSAT, EVS_LIVE_SAT, EVS_ABSENT = 0, 1, 2, 3
 
 HDR_DT = np.dtype([("magic", "<u8"), ("n_edt", "<u4"), ("n_evt", "<u4"), ("n_db", "<u4"),
-                   ("n_main", "<u4"), ("n_script", "<u4"), ("sink_edt", "<u4"), ("pad", "<u4", 8)])
+                   ("n_main", "<u4"), ("n_script", "<u4"), ("sink_edt", "<u4"), ("db_words", "<u4"), ("pad", "<u4", 7)])
 EDT_DT = np.dtype([("depc", "<u4"), ("body", "<u4"), ("script_begin", "<u4"), ("script_len", "<u4")])
 EVT_DT = np.dtype([("kind", "<u4"), ("arg", "<i4")])
 OP_DT = np.dtype([("op", "u1"), ("mode", "u1"), ("pad", "<u2"), ("slot", "<u4"), ("a", "<u8"), ("b", "<u8")])
@@ -65,7 +65,8 @@ def make_ops(op, a, b=0, slot=0, mode=0):
 class OpStream:
     """SoA container for one program. ``main`` and ``script`` are OP_DT arrays."""
 
-    def __init__(self, edt, evt, db_init, main, script, sink_edt, name="", meta=None):
+    def __init__(self, edt, evt, db_init, main, script, sink_edt, name="", meta=None, db_words=0):
+        self.db_words = int(db_words)   # 0: datablocks are {value, id}; 64: each also carries an 8x8 int64 tile (OCRBODY_TILE)
         self.edt = np.ascontiguousarray(edt, dtype=EDT_DT)
         self.evt = np.ascontiguousarray(evt, dtype=EVT_DT)
         self.db_init = np.ascontiguousarray(db_init, dtype=np.uint64)
@@ -81,16 +82,25 @@ class OpStream:
     n_evt_total = property(lambda s: len(s.evt) + len(s.edt))
     n_db_total = property(lambda s: len(s.db_init) + len(s.edt))
 
+    def with_main(self, main):
+        """The same program with another main-op list (e.g. without its last op, the start satisfy)."""
+        return OpStream(self.edt, self.evt, self.db_init, main, self.script, self.sink_edt, name=self.name, meta=self.meta,
+                        db_words=self.db_words)
+
+    def header(self):
+        hdr = np.zeros(1, dtype=HDR_DT)
+        hdr["magic"] = MAGIC
+        hdr["n_edt"], hdr["n_evt"], hdr["n_db"] = self.n_edt, self.n_evt, self.n_db
+        hdr["n_main"], hdr["n_script"], hdr["sink_edt"], hdr["db_words"] = len(self.main), len(self.script), self.sink_edt, self.db_words
+        return hdr
+
     def n_satisfy_ops(self):
         """Dependence satisfactions a full resolve applies (SURVEY.md s8d metric numerator):
         every (dst,slot) satisfy applied to an EDT pre-slot or an event pre-slot."""
         return self.meta.get("n_satisfactions")
 
     def to_file(self, path):
-        hdr = np.zeros(1, dtype=HDR_DT)
-        hdr["magic"] = MAGIC
-        hdr["n_edt"], hdr["n_evt"], hdr["n_db"] = self.n_edt, self.n_evt, self.n_db
-        hdr["n_main"], hdr["n_script"], hdr["sink_edt"] = len(self.main), len(self.script), self.sink_edt
+        hdr = self.header()
         with open(path, "wb") as f:
             for arr in (hdr, self.edt, self.evt, self.db_init, self.main, self.script):
                 f.write(arr.tobytes())
@@ -107,7 +117,7 @@ class OpStream:
             nb = int(n) * dt.itemsize
             out.append(buf[off:off + nb].view(dt).copy())
             off += nb
-        return cls(out[0], out[1], out[2], out[3], out[4], int(hdr["sink_edt"]))
+        return cls(out[0], out[1], out[2], out[3], out[4], int(hdr["sink_edt"]), db_words=int(hdr["db_words"]))
 
 
 class Result:
@@ -441,7 +451,7 @@ def split_conflicts(keys):
 
 
 def _finish_stream(N, depc, src_ref, dst_idx, slot, mode, extra_main=(), evt_extra=(), name="", meta=None,
-                   bodies=None, db_init=None, start_targets=None):
+                   bodies=None, db_init=None, start_targets=None, db_words=0):
     """Common tail of the bulk generators: EDTs 0..N-1 (HASH bodies, ONCE output events) with dependences
     (src_ref[i] -> EDT dst_idx[i], slot[i], mode[i]); EDTs in ``start_targets`` take the start event on their LAST
     pre-slot; output events nobody consumes DECR the sink latch; sink EDT = N.  Events: 0 = start (ONCE), 1 = sink
@@ -478,14 +488,19 @@ def _finish_stream(N, depc, src_ref, dst_idx, slot, mode, extra_main=(), evt_ext
     main = np.concatenate([p for p in parts if len(p)])
     m = dict(meta or {})
     m.update(n_leaves=len(leaves), n_satisfactions=int(np.asarray(depc, dtype=np.int64).sum()) + 1 + len(leaves))
-    return OpStream(edt, evt, db_init, main, np.zeros(0, dtype=OP_DT), N, name=name, meta=m)
+    return OpStream(edt, evt, db_init, main, np.zeros(0, dtype=OP_DT), N, name=name, meta=m, db_words=db_words)
 
 
-def cholesky_dag(T: int, name=None) -> OpStream:
+def cholesky_dag(T: int, name=None, tiles=False) -> OpStream:
     """BASELINE config 3: right-looking tiled Cholesky, T tiles per side, datablock-carried
     dependences.  potrf(k) <- syrk(k-1,k); trsm(k,i) <- potrf(k), gemm(k-1,i,k); syrk(k,i) <- trsm(k,i), syrk(k-1,i);
     gemm(k,i,j) <- trsm(k,i), trsm(k,j), gemm(k-1,i,j)   (i > j > k).  At k = 0 the "previous update" is the initial
-    tile, an explicit DB added with ocrAddDependence(db, edt, slot).  T + T(T-1) + T(T-1)(T-2)/6 EDTs, fan-in <= 3."""
+    tile, an explicit DB added with ocrAddDependence(db, edt, slot).  T + T(T-1) + T(T-1)(T-2)/6 EDTs, fan-in <= 3.
+
+    ``tiles=False``: HASH bodies (every task folds its inputs into a new 16-byte datablock).  ``tiles=True``: the payload
+    s8d.3 names -- one datablock per tile holding an 8x8 tile of 64-bit integers, updated IN PLACE by TILE bodies (the task's
+    last tile -= first * second^T over wrapping integers; the task returns the tile it updated, so the same T*T datablocks
+    travel down the task chains) -- checksums are exact."""
     k_, i_ = np.triu_indices(T, 1)                       # pairs k < i
     nP, nTr = T, len(k_)
     gi, gj, gk = [], [], []
@@ -541,6 +556,9 @@ def cholesky_dag(T: int, name=None) -> OpStream:
     depc[first] += 1
     db_init = splitmix64(SEED_BASE + 3, T * T)
     mode = np.where(ref_cls(src) == REF_DB, MODE_RO, MODE_RW).astype(np.uint8)
+    if tiles:
+        return _finish_stream(N, depc, src, dst, slot, mode, name=name or f"cholesky_tiles_T{T}", db_init=db_init, start_targets=first,
+                              meta=dict(kind="cholesky_tiles", T=T), bodies=BODY_TILE | BODY_F_OUTEVT, db_words=64)
     return _finish_stream(N, depc, src, dst, slot, mode, name=name or f"cholesky_T{T}", db_init=db_init,
                           start_targets=first, meta=dict(kind="cholesky", T=T))
 

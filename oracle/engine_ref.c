@@ -70,6 +70,7 @@ typedef struct {
     work_t *stack; size_t sp, stack_cap;
     uint32_t *ready_next; size_t n_next, cap_next;
     uint64_t *db_val; uint8_t *db_live;
+    uint64_t *tiles;     /* hdr.db_words == 64: the 8x8 tile behind every created datablock (OCRBODY_TILE) */
     uint64_t err[N_ERR], n_edge_sat, n_evt_sat;
     int lockable; dblock_t *dbl; uint32_t *acq; size_t n_acq, cap_acq; /* acq: EDTs whose datablock frontier is to be (re)started */
 } eng_t;
@@ -323,6 +324,20 @@ static void fire(eng_t *E, uint32_t e, int32_t lvl, int32_t *level, uint64_t *va
     }
     level[e] = lvl; val[e] = v;
     uint32_t ret = 0;
+    if (OCRBODY_KIND(d->body) == OCRBODY_TILE) { /* the last tile on the pre-slots is updated in place with the ones before it */
+        uint32_t t[3], n = 0;
+        for (uint32_t i = 0; i < d->depc; ++i) {
+            uint32_t p = depv[i].payload;
+            if (!p) continue;
+            if (!E->tiles || p - 1 >= E->h->n_db || n == 3) { E->err[ERR_BAD_OP]++; n = 0; break; }
+            t[n++] = p;
+        }
+        if (n) {
+            val[e] = ocrops_tile_update(E->tiles + 64 * (size_t)(t[n - 1] - 1), n >= 2 ? E->tiles + 64 * (size_t)(t[0] - 1) : NULL,
+                                        n == 3 ? E->tiles + 64 * (size_t)(t[1] - 1) : NULL);
+            ret = t[n - 1];
+        } else val[e] = 0;
+    }
     switch (OCRBODY_KIND(d->body)) {
     case OCRBODY_HASH: ret = E->h->n_db + e + 1; E->db_val[ret - 1] = v; E->db_live[ret - 1] = 1; break;
     case OCRBODY_FWD0: ret = d->depc ? depv[0].payload : 0; break;
@@ -363,6 +378,7 @@ int ocrref_run2(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt
     E.slots = calloc(ns + 1, sizeof(slot_t));
     E.db_val = db_val; memset(db_val, 0, 8 * (size_t)n_db_total);
     E.db_live = calloc(n_db_total + 1, 1);
+    if (h->db_words == OCROPS_TILE_WORDS) E.tiles = calloc(64 * (size_t)h->n_db + 1, 8);
     if (E.lockable) E.dbl = calloc(n_db_total + 1, sizeof(dblock_t));
     for (uint32_t x = 0; x < n_evt_total; ++x) E.ev[x].state = ST_ABSENT;
     memset(level, 0xFF, 4 * (size_t)h->n_edt); memset(val, 0, 8 * (size_t)h->n_edt);
@@ -372,7 +388,9 @@ int ocrref_run2(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt
         switch (op->op) {
         case OCROP_EVT_CREATE: { event_t *v = &E.ev[op->a]; v->kind = evt[op->a].kind; v->state = ST_LIVE;
                                   v->counter = (v->kind == OCREVT_LATCH || v->kind == OCREVT_COUNTED || v->kind == OCREVT_CHANNEL) ? evt[op->a].arg : 0; } break; /* CHANNEL: maxGen */
-        case OCROP_DB_CREATE: E.db_val[op->a] = db_init[op->a]; E.db_live[op->a] = 1; break;
+        case OCROP_DB_CREATE: E.db_val[op->a] = db_init[op->a]; E.db_live[op->a] = 1;
+                              if (E.tiles) for (uint32_t w = 0; w < 64; ++w) E.tiles[64 * (size_t)op->a + w] = ocrops_tile_init(db_init[op->a], w);
+                              break;
         case OCROP_EDT_CREATE: { uint32_t e = (uint32_t)op->a; E.ed[e].created = 1;
                                   if (edt[e].body & OCRBODY_F_OUTEVT) { event_t *v = &E.ev[h->n_evt + e]; v->kind = OCREVT_ONCE; v->state = ST_LIVE; }
                                   if (edt[e].depc == 0) push_ready(&E, e); } break; /* nothing to acquire */
@@ -404,6 +422,7 @@ int ocrref_run2(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt
         }
         free(v->w); free(v->sq);
     }
+    if (E.tiles) { for (uint32_t d = 0; d < h->n_db; ++d) if (E.db_live[d]) db_val[d] = ocrops_tile_checksum(E.tiles + 64 * (size_t)d); free(E.tiles); }
     if (stats) { memset(stats, 0, 16 * 8); stats[0] = (uint64_t)lvl; stats[1] = fired; stats[2] = E.n_edge_sat; stats[3] = E.n_evt_sat;
                  for (int i = 0; i < N_ERR; ++i) stats[8 + i] = E.err[i]; }
     for (uint32_t i = 0; i < h->n_edt; ++i) free(E.ed[i].order);

@@ -209,6 +209,13 @@ static ocrGuid_t bodyEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) 
         struct timespec ts = { 0, 20000 }; nanosleep(&ts, NULL); /* stay inside long enough for an unkept exclusion to show */
     }
     ocrGuid_t ret = NULL_GUID;
+    if (OCRBODY_KIND(e->body) == OCRBODY_TILE) { /* the last tile on the pre-slots is updated in place with the ones before it */
+        uint64_t *t[3]; ocrGuid_t tg[3]; uint32_t n = 0;
+        for (u32 i = 0; i < depc && n < 3; ++i) if (depv[i].ptr != NULL) { t[n] = (uint64_t *)depv[i].ptr + 2; tg[n++] = depv[i].guid; }
+        if (G.hdr.db_words != OCROPS_TILE_WORDS) { fprintf(stderr, "replay: TILE body in a stream without tile datablocks\n"); abort(); }
+        v = n ? ocrops_tile_update(t[n - 1], n >= 2 ? t[0] : NULL, n == 3 ? t[1] : NULL) : 0;
+        if (n) ret = tg[n - 1];
+    }
     switch (OCRBODY_KIND(e->body)) {
     case OCRBODY_HASH: {
         uint64_t *p; ocrGuid_t g;
@@ -303,7 +310,11 @@ static void dump_results(void) {
     fwrite(G.level, 4, G.hdr.n_edt, f);
     fwrite(G.val, 8, G.hdr.n_edt, f);
     for (uint32_t x = 0; x < G.n_evt_total; ++x) { uint64_t s = dump_event_state(pd, x); fwrite(&s, 8, 1, f); }
-    for (uint32_t d = 0; d < G.n_db_total; ++d) { uint64_t v = G.db_ptr[d] ? G.db_ptr[d][0] : 0; fwrite(&v, 8, 1, f); }
+    for (uint32_t d = 0; d < G.n_db_total; ++d) {
+        uint64_t v = G.db_ptr[d] ? G.db_ptr[d][0] : 0;
+        if (G.db_ptr[d] && d < G.hdr.n_db && G.hdr.db_words == OCROPS_TILE_WORDS) v = ocrops_tile_checksum(G.db_ptr[d] + 2); /* tile datablocks report their contents */
+        fwrite(&v, 8, 1, f);
+    }
     fclose(f);
 }
 
@@ -415,8 +426,9 @@ ocrGuid_t mainEdt(u32 paramc, u64 *paramv, u32 depc, ocrEdtDep_t depv[]) {
         } break;
         case OCROP_DB_CREATE: {
             uint32_t d = (uint32_t)op->a; uint64_t *p;
-            ocrDbCreate(&G.db_guid[d], (void **)&p, 16, 0, NULL_HINT, NO_ALLOC);
+            ocrDbCreate(&G.db_guid[d], (void **)&p, 16 + 8 * G.hdr.db_words, 0, NULL_HINT, NO_ALLOC);
             p[0] = G.db_init[d]; p[1] = d; G.db_ptr[d] = p;
+            for (uint32_t w = 0; w < G.hdr.db_words; ++w) p[2 + w] = ocrops_tile_init(G.db_init[d], w);
             ocrDbRelease(G.db_guid[d]);
         } break;
         case OCROP_EDT_CREATE: {

@@ -55,10 +55,7 @@ def _p(a):
 def run_restatement(s: OpStream, return_stats=False, lockable=False):
     """``lockable``: datablocks arbitrate their acquire modes like the cfg's datablockfactory=Lockable (else Regular)."""
     lib = _load()
-    hdr = np.zeros(1, dtype=HDR_DT)
-    hdr["magic"] = MAGIC
-    hdr["n_edt"], hdr["n_evt"], hdr["n_db"] = s.n_edt, s.n_evt, s.n_db
-    hdr["n_main"], hdr["n_script"], hdr["sink_edt"] = len(s.main), len(s.script), s.sink_edt
+    hdr = s.header()
     level = np.empty(s.n_edt, dtype=np.int32)
     val = np.empty(s.n_edt, dtype=np.uint64)
     evs = np.empty(s.n_evt_total, dtype=np.uint64)

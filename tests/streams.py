@@ -157,13 +157,15 @@ def counted_after_null_preslot():
     b = Builder("counted_after_null_preslot")
     start = b.evt(EVT_ONCE)
     x = b.evt(EVT_ONCE)
-    e0 = b.edt(2)
+    e0 = b.edt(3)
     b.add_dep(x, e0, 0, MODE_NULL)
     b.satisfy(x, 0)                        # pre-slot 0 is satisfied before the COUNTED source exists
     c0 = b.evt(EVT_COUNTED, 1)
     b.add_dep(c0, e0, 1, MODE_RO)
     d = b.db(0x7777)
-    b.satisfy(c0, d)                       # serves its one registration: destroyed, e0 is ready
+    b.satisfy(c0, d)                       # serves its one registration: destroyed
+    b.add_dep(start, e0, 2, MODE_NULL)     # (e0 waits for the start event like everybody: an EDT that became ready while the main
+                                           #  program is still registering waiters on its output event is a race with >1 worker)
     y = b.evt(EVT_ONCE)
     e1 = b.edt(3)
     b.add_dep(y, e1, 0, MODE_NULL)
@@ -559,6 +561,9 @@ def all_streams():
     # small twins of BASELINE configs 3, 4 and 5
     out.append(cholesky_dag(8, name="cholesky_T8"))
     out.append(cholesky_dag(32, name="cholesky_T32"))
+    # ... and config 3 with the payload s8d.3 names: 8x8 int64 tile datablocks updated in place by TILE bodies
+    out.append(cholesky_dag(8, tiles=True))
+    out.append(cholesky_dag(32, tiles=True))
     out.append(stencil_dag(16, 10, name="stencil_16x16x10"))
     out.append(powerlaw_dag(100_000, name="powerlaw_100k"))
     return out

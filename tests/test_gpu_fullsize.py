@@ -21,7 +21,7 @@ def _full_parity(s, rearm=True):
     want = O.run_restatement(s)
     assert want.n_fired == s.n_edt
     start_op = s.main[-1:]
-    built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
+    built = s.with_main(s.main[:-1])
     p = engine.StreamProgram(built, flags=0).build()
     p.eng.snapshot()
     start = p._guids(start_op["a"])
@@ -45,6 +45,17 @@ def _full_parity(s, rearm=True):
 def test_config3_cholesky_T256_full_size():
     s = opstream.cholesky_dag(256)
     assert s.n_edt == 2_829_057                      # potrf 256 + trsm, syrk 32 640 each + gemm 2 763 520 + sink
+    want = _full_parity(s)
+    assert int(want.level.max()) + 1 == 767
+
+
+def test_config3_cholesky_T256_tile_datablocks():
+    """The same DAG with the payload SURVEY.md s8d.3 names: 65 536 datablocks of 528 bytes (an 8x8 tile of 64-bit integers
+    each), updated in place by TILE bodies (tile -= first * second^T, wrapping), the updated datablock travelling on through
+    the task's output event.  Every task's tile checksum, every level and the final contents of every tile against the
+    restatement (whose T = 8 and T = 32 twins are pinned to the reference runtime: tests/golden/cholesky_tiles_T*)."""
+    s = opstream.cholesky_dag(256, tiles=True)
+    assert s.n_edt == 2_829_057 and s.n_db == 65_536 and s.db_words == 64
     want = _full_parity(s)
     assert int(want.level.max()) + 1 == 767
 

@@ -21,6 +21,8 @@ def make(spec):
     a = [int(x) for x in a]
     if k == "cholesky":
         return op.cholesky_dag(a[0])
+    if k == "choleskytiles":   # config 3 with 8x8 int64 tile datablocks updated in place (OCRBODY_TILE)
+        return op.cholesky_dag(a[0], tiles=True)
     if k == "stencil":
         return op.stencil_dag(a[0], a[1])
     if k == "powerlaw":
@@ -64,7 +66,7 @@ def run(spec, steps=3, warmup=1, parity=True):
     stage(f"{spec}: generated {s.n_edt} EDTs, {len(s.main)} main ops in {gen_s:.1f} s")
     assert int(s.main["op"][-1]) == ops.OP_SATISFY, "generators end with the start satisfy"
     start_op = s.main[-1:]
-    built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
+    built = s.with_main(s.main[:-1])
     t0 = time.time()
     lockable = spec.startswith("lockable")
     prog = engine.StreamProgram(built, device=0, flags=engine.F_TIMING | (engine.F_LOCKABLE_DB if lockable else 0)).build()

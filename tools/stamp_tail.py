@@ -65,7 +65,7 @@ if __name__ == "__main__":
     from ocr_amd import engine, opstream
     n, w = int(os.environ.get("STAMP_N", 10_000_000)), int(os.environ.get("STAMP_W", 10_000))   # a wide level: STAMP_W=100000
     s = opstream.layered_dag(n, w)
-    built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
+    built = s.with_main(s.main[:-1])
     prog = engine.StreamProgram(built, device=0, flags=0).build()
     eng = prog.eng
     eng.snapshot()

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import torch
 from ocr_amd import engine, opstream
 s = opstream.layered_dag(2_000_000, 10_000)
-built = opstream.OpStream(s.edt, s.evt, s.db_init, s.main[:-1], s.script, s.sink_edt)
+built = s.with_main(s.main[:-1])
 prog = engine.StreamProgram(built, device=0, flags=0).build()
 eng = prog.eng
 eng.snapshot()
