@@ -21,9 +21,13 @@
  * INCR when a child is created in the scope, DECR in every child's epilogue and in the finish EDT's own; the latch
  * satisfies the finish EDT's output event and DECRs the enclosing scope's latch.
  *
- * Not thread safe; bodies run on the calling thread.  No CPU fallback: without a GPU ocrgpu_init fails and the
- * program exits with an error.
+ * Worker threads (hc-worker.c:52-265): with OCRSHIM_WORKERS=N > 1 the bodies of one level (they are independent by
+ * construction) are run by N threads; each body's deferred calls go to its thread's own queue (the per-body program-order
+ * state is thread-local) and are merged when the level is done; the engine is still driven by one thread at a time (the
+ * shared host tables and the few engine calls a body can cause -- guid blocks -- sit behind one mutex).  Default: 1.
+ * No CPU fallback: without a GPU ocrgpu_init fails and the program exits with an error.
  */
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -49,6 +53,12 @@ static void *xrealloc(void *p, size_t n) { void *q = realloc(p, n ? n : 1); if (
 #define CHK(call) do { int _rc = (call); if (_rc && _rc != OCRGPU_EFAULT) die("%s failed (%d): %s", #call, _rc, ocrgpu_last_error()); } while (0)
 
 static ocrgpu_engine_t *G;
+/* one mutex for the host tables bodies share (tasks, templates, guid pools, datablock map, labels, ranges) and for the
+ * engine calls made from inside a body; uncontended (and free of any other thread) unless OCRSHIM_WORKERS > 1 */
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+#define LOCK() pthread_mutex_lock(&g_mu)
+#define UNLOCK() pthread_mutex_unlock(&g_mu)
+#define TLS __thread
 static int g_shutdown, g_exit_code, g_verbose;
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
@@ -59,9 +69,12 @@ enum { POOL_BLOCK = 4096 };
 typedef struct { u64 g[POOL_BLOCK]; u32 next, n; } Pool;
 static Pool pools[32];
 static u64 pool_take(u32 kind) {
+    LOCK();
     Pool *p = &pools[kind];
     if (p->next == p->n) { CHK(ocrgpu_guid_reserve(G, kind, POOL_BLOCK, p->g, OCRGPU_HOST)); p->next = 0; p->n = POOL_BLOCK; }
-    return p->g[p->next++];
+    const u64 g = p->g[p->next++];
+    UNLOCK();
+    return g;
 }
 
 /* ---- templates and tasks (host metadata: what ocrTaskTemplateHc_t / ocrTaskHc_t keep for taskExecute) ------- */
@@ -72,6 +85,7 @@ typedef struct {
     u64 scope_latch;   /* latch of the finish scope this EDT was created in (0 = none): DECR in its epilogue */
     u64 own_latch;     /* EDT_PROP_FINISH: the latch of the scope it opens                                   */
     u8 ran, destroyed;
+    u64 creator;       /* serial of the body that created it (its check-in is issued when that body returns) */
 } Task;
 static Template *tpls; static size_t n_tpl, cap_tpl;
 static Task *tasks; static size_t n_task, cap_task;
@@ -112,22 +126,23 @@ static u64 db_len(const void *p) { return p ? *(const u64 *)((const char *)p - 1
 /* ---- the deferred-op queue ---------------------------------------------------------------------------------- */
 enum { C_EVT_CREATE, C_DB_CREATE, C_EDT_CREATE, C_ADD_DEP, C_SATISFY, C_EVT_DESTROY, C_DB_DESTROY, N_CLASS };
 typedef struct { u8 cls, mode; u16 pad; u32 slot; u32 round; s32 arg; u64 a, b, c; u64 seq; } Op;
-static Op *ops; static size_t n_ops, cap_ops;
+static TLS Op *ops; static TLS size_t n_ops, cap_ops;   /* the running thread's queue */
 static u64 flush_epoch;          /* bumped by every flush(): tells whether a labeled create is still in the queue */
 /* per-body program-order state */
-static u32 cur_round; static int cur_cls;
+static TLS u32 cur_round; static TLS int cur_cls;
 typedef struct { u64 evt; u32 slot; } Touched;
-static Touched *touched; static size_t n_touched, cap_touched;   /* events satisfied in the current round by this body */
-static Task *cur_task;            /* EDT whose body is running (NULL while mainEdt runs) */
-static u64 cur_scope;             /* latch of the finish scope children are created in   */
-static u32 pending_checkins;      /* children created in cur_scope by this body: INCRs issued when the body returns */
-static size_t body_first_task;    /* tasks[body_first_task..] were created by the running body */
+static TLS Touched *touched; static TLS size_t n_touched, cap_touched;   /* events satisfied in the current round by this body */
+static TLS Task *cur_task;            /* EDT whose body is running (NULL while mainEdt runs) */
+static TLS u64 cur_scope;             /* latch of the finish scope children are created in   */
+static TLS u32 pending_checkins;      /* children created in cur_scope by this body: INCRs issued when the body returns */
+static TLS u64 cur_body;          /* serial of the running body (Task.creator of what it creates) */
+static u64 body_serial;
 
 static u64 init_epoch;            /* bumped by every bring-up (legacy blocks bring the runtime up more than once) */
 static void els_reset(void);
 static void body_begin(Task *t) {
     els_reset();
-    cur_round = 0; cur_cls = -1; n_touched = 0; cur_task = t; pending_checkins = 0; body_first_task = n_task;
+    cur_round = 0; cur_cls = -1; n_touched = 0; cur_task = t; pending_checkins = 0; cur_body = __sync_add_and_fetch(&body_serial, 1);
     cur_scope = t ? (t->own_latch ? t->own_latch : t->scope_latch) : 0;
 }
 static Op *emit(int cls) {
@@ -222,7 +237,7 @@ static void batch_room(size_t n) {
  * left, the rows of finished EDTs and destroyed events are taken back first (ocrgpu_reclaim).  Only between levels and with
  * no body on the stack (a body blocked in ocrLegacyBlockProgress has been handed out but has not returned). */
 static u64 room[4];               /* rows / registrations the engine can still take: EDTs, events, datablocks, edges */
-static int run_depth;             /* bodies on the stack */
+static TLS int run_depth;         /* bodies on this thread's stack */
 static u64 n_reclaims, peak_live_edt, cap_edt;
 static void make_room(void) {
     u64 want[4] = {0, 0, 0, 0};
@@ -315,7 +330,9 @@ static size_t labset_find(u64 g) { /* slot of g, or of the free slot where it wo
 /* 1 = the label is free (never used, or its object was destroyed) and is now taken by the running body.  0 = it is
  * in use; if its create is still queued (another EDT of this level made it), the running body's later ops are moved
  * to that create's round so that they reach the engine after it. */
-static int labset_add(u64 g, int cls) {
+static int labset_add_locked(u64 g, int cls);
+static int labset_add(u64 g, int cls) { LOCK(); const int r = labset_add_locked(g, cls); UNLOCK(); return r; }
+static int labset_add_locked(u64 g, int cls) {
     if (2 * (labset_n + 1) > labset_cap) {
         size_t oc = labset_cap; u64 *old = labset, *olde = labepoch; u8 *olda = labalive; u32 *oldr = labround;
         labset_cap = oc ? 2 * oc : 1024;
@@ -336,7 +353,7 @@ static int labset_add(u64 g, int cls) {
     labalive[h] = 1; labround[h] = (cur_round << 3) | (u32)cls; labepoch[h] = flush_epoch; /* where emit(cls) will put it */
     return 1;
 }
-static void labset_release(u64 g) { if (labset_cap) { size_t h = labset_find(g); if (labset[h] == g) labalive[h] = 0; } }
+static void labset_release(u64 g) { LOCK(); if (labset_cap) { size_t h = labset_find(g); if (labset[h] == g) labalive[h] = 0; } UNLOCK(); }
 /* what a create call does with GUID_PROP_IS_LABELED: *guid is an input; 0 = go on and create at `out` */
 static u8 labeled_guid(const ocrGuid_t *guid, u16 props, u32 want_kind, int cls, u64 *out) {
     if (!(props & GUID_PROP_IS_LABELED)) { *out = 0; return 0; }
@@ -349,6 +366,7 @@ static u8 labeled_guid(const ocrGuid_t *guid, u16 props, u32 want_kind, int cls,
 static u8 range_new(ocrGuid_t *out, u64 n, ocrGuidUserKind kind, ocrGuidMapFunc_t fn, s64 *params, u32 numParams) {
     if (!out || n == 0 || kind == GUID_USER_NONE || kind == GUID_USER_EDT_TEMPLATE || (u32)kind >= 32) return OCR_EINVAL;
     u64 *tmp = xrealloc(NULL, 8 * (size_t)n);
+    LOCK();
     CHK(ocrgpu_guid_reserve(G, (u32)kind, n, tmp, OCRGPU_HOST));   /* consecutive counters: first + i */
     GROW(ranges, n_range, cap_range);
     Range *r = &ranges[n_range];
@@ -356,12 +374,17 @@ static u8 range_new(ocrGuid_t *out, u64 n, ocrGuidUserKind kind, ocrGuidMapFunc_
     if (numParams && params) { r->params = xrealloc(NULL, 8 * (size_t)numParams); memcpy(r->params, params, 8 * (size_t)numParams); }
     free(tmp);
     out->guid = (intptr_t)(((u64)KIND_GUIDMAP << 49) | (u64)(++n_range));
+    UNLOCK();
     return 0;
 }
-static Range *range_of(ocrGuid_t g) {
+static Range *range_of(ocrGuid_t g) { /* a copy: the table may move while another body creates a range */
+    static TLS Range copy;
     u64 v = (u64)g.guid;
-    if (OCRGPU_GUID_KIND(v) != KIND_GUIDMAP || (v & 0xFFFFFFFFu) == 0 || (v & 0xFFFFFFFFu) > n_range) return NULL;
-    return &ranges[(v & 0xFFFFFFFFu) - 1];
+    Range *r = NULL;
+    LOCK();
+    if (OCRGPU_GUID_KIND(v) == KIND_GUIDMAP && (v & 0xFFFFFFFFu) != 0 && (v & 0xFFFFFFFFu) <= n_range) { copy = ranges[(v & 0xFFFFFFFFu) - 1]; r = &copy; }
+    UNLOCK();
+    return r;
 }
 u8 ocrGuidRangeCreate(ocrGuid_t *rangeGuid, u64 n, ocrGuidUserKind kind) { return range_new(rangeGuid, n, kind, NULL, NULL, 0); }
 u8 ocrGuidMapCreate(ocrGuid_t *mapGuid, u32 numParams, ocrGuidMapFunc_t fn, s64 *params, u64 n, ocrGuidUserKind kind) {
@@ -423,7 +446,7 @@ u8 ocrGetHint(ocrGuid_t guid, ocrHint_t *h) { (void)guid; if (!h) return OCR_EIN
 
 /* ---- runtime interface extension (ocr/inc/extensions/ocr-runtime-itf.h): one worker, EDT-local storage per body ---- */
 #include "extensions/ocr-runtime-itf.h"
-static ocrGuid_t els_slots[OCRSHIM_ELS_SLOTS];   /* cleared by body_begin */
+static TLS ocrGuid_t els_slots[OCRSHIM_ELS_SLOTS];   /* cleared by body_begin */
 static void els_reset(void) { memset(els_slots, 0, sizeof els_slots); }
 ocrGuid_t ocrElsUserGet(u8 offset) { return offset < OCRSHIM_ELS_SLOTS ? els_slots[offset] : NULL_GUID; }
 void ocrElsUserSet(u8 offset, ocrGuid_t data) { if (offset < OCRSHIM_ELS_SLOTS) els_slots[offset] = data; }
@@ -495,7 +518,7 @@ u8 ocrDbCreate(ocrGuid_t *db, void **addr, u64 len, u16 flags, ocrHint_t *hint, 
     if (!p) return OCR_ENOMEM;
     Op *o = emit(C_DB_CREATE);
     o->a = lg ? lg : pool_take(OCRGPU_KIND_DB); o->b = (u64)(uintptr_t)p;
-    dbmap_put(o->a, p);
+    LOCK(); dbmap_put(o->a, p); UNLOCK();
     db->guid = (intptr_t)o->a; *addr = (flags & DB_PROP_NO_ACQUIRE) ? NULL : p; /* ocr-db.h:60-64 */
     return 0;
 }
@@ -505,25 +528,31 @@ u8 ocrDbDestroy(ocrGuid_t db) { Op *o = emit(C_DB_DESTROY); o->a = (u64)db.guid;
 u8 ocrEdtTemplateCreate_internal(ocrGuid_t *guid, ocrEdt_t fn, u32 paramc, u32 depc, const char *name) {
     (void)name;
     if (!guid || !fn) return OCR_EINVAL;
+    LOCK();
     GROW(tpls, n_tpl, cap_tpl);
     tpls[n_tpl].fn = fn; tpls[n_tpl].paramc = paramc; tpls[n_tpl].depc = depc;
     guid->guid = (intptr_t)tpl_guid(n_tpl++);
+    UNLOCK();
     return 0;
 }
 u8 ocrEdtTemplateDestroy(ocrGuid_t guid) { (void)guid; return 0; }
 /* ocrEdtDestroy of an EDT that has not run (destructTaskHc, hc-task.c:760-790): it leaves its finish scope */
 u8 ocrEdtDestroy(ocrGuid_t guid) {
+    LOCK();
     for (size_t i = n_task; i-- > 0;) {
         Task *t = &tasks[i];
         if (t->guid != (u64)guid.guid) continue;
-        if (t->ran || t->destroyed) return 0;
+        if (t->ran || t->destroyed) { UNLOCK(); return 0; }
         t->destroyed = 1;
-        if (t->scope_latch) {
-            if (i >= body_first_task && pending_checkins) --pending_checkins; /* its check-in has not been issued yet */
-            else emit_satisfy(t->scope_latch, 0, OCRLATCH_DECR);
+        const u64 latch = t->scope_latch; const int mine = t->creator == cur_body;
+        UNLOCK();
+        if (latch) {
+            if (mine && pending_checkins) --pending_checkins; /* its check-in has not been issued yet */
+            else emit_satisfy(latch, 0, OCRLATCH_DECR);
         }
         return 0;
     }
+    UNLOCK();
     return OCR_EINVAL;
 }
 
@@ -532,8 +561,10 @@ u8 ocrEdtCreate(ocrGuid_t *guid, ocrGuid_t tplGuid, u32 paramc, u64 *paramv, u32
                 ocrHint_t *hint, ocrGuid_t *outputEvent) {
     (void)hint;
     u64 tg = (u64)tplGuid.guid;
-    if (OCRGPU_GUID_KIND(tg) != KIND_TEMPLATE || (tg & 0xFFFFFFFFu) == 0 || (tg & 0xFFFFFFFFu) > n_tpl) return OCR_EINVAL;
-    const Template *tp = &tpls[(tg & 0xFFFFFFFFu) - 1];
+    LOCK();
+    if (OCRGPU_GUID_KIND(tg) != KIND_TEMPLATE || (tg & 0xFFFFFFFFu) == 0 || (tg & 0xFFFFFFFFu) > n_tpl) { UNLOCK(); return OCR_EINVAL; }
+    const Template tpl_copy = tpls[(tg & 0xFFFFFFFFu) - 1], *tp = &tpl_copy; /* (the table may move while another body creates a template) */
+    UNLOCK();
     if (paramc == EDT_PARAM_DEF) paramc = tp->paramc;
     if (depc == EDT_PARAM_DEF) depc = tp->depc;
     if (paramc == EDT_PARAM_UNK || depc == EDT_PARAM_UNK) return OCR_EINVAL;            /* ocr-edt.c:330-360 */
@@ -542,22 +573,21 @@ u8 ocrEdtCreate(ocrGuid_t *guid, ocrGuid_t tplGuid, u32 paramc, u64 *paramv, u32
     const int finish = (props & EDT_PROP_FINISH) != 0;
     const int want_out = outputEvent != NULL || finish;
 
-    GROW(tasks, n_task, cap_task);
-    const size_t ti = n_task++;
-    Task *t = &tasks[ti];
+    Task nt, *t = &nt; /* filled here, entered into the table (which other bodies may be growing) in one step below */
     memset(t, 0, sizeof *t);
+    t->creator = cur_body;
     t->fn = tp->fn; t->paramc = paramc; t->depc = depc;
     if (paramc) { t->paramv = xrealloc(NULL, 8 * (size_t)paramc); memcpy(t->paramv, paramv, 8 * (size_t)paramc); }
     u64 lg = 0;
     if (props & GUID_PROP_IS_LABELED) { /* the EDT is created at *guid; depv is ignored (ocr-edt.c:323-330) */
         u8 lr = guid ? labeled_guid(guid, props, OCRGPU_KIND_EDT, C_EDT_CREATE, &lg) : OCR_EINVAL;
-        if (lr) { free(t->paramv); --n_task; return lr; }
+        if (lr) { free(t->paramv); return lr; }
         depv = NULL;
     }
     t->guid = lg ? lg : pool_take(OCRGPU_KIND_EDT);
     /* EDT_PROP_OEVT_VALID (ocr-edt.c:378-386, hc-task.c:940-959): the caller's own event takes the place of the ONCE */
     const int own_evt = (props & EDT_PROP_OEVT_VALID) && outputEvent && outputEvent->guid != 0 && outputEvent->guid != -1 && outputEvent->guid != -2;
-    if ((props & EDT_PROP_OEVT_VALID) && !own_evt) { --n_task; return OCR_EINVAL; }
+    if ((props & EDT_PROP_OEVT_VALID) && !own_evt) { free(t->paramv); return OCR_EINVAL; }
     t->outevt = own_evt ? (u64)outputEvent->guid : want_out ? pool_take(OCRGPU_KIND_EVT_ONCE) : 0;
     t->scope_latch = cur_scope;
     if (finish) { /* the scope's latch starts at 1: the finish EDT itself (hc-task.c:1931-1933) */
