@@ -67,14 +67,17 @@ static double t_sort, t_calls, t_step, t_pop, t_bodies; /* OCRSHIM_VERBOSE: wher
 /* ---- guid pools: blocks of reserved guids per kind (guidReserve, ocr-guid.h:127-144) ------------------------ */
 enum { POOL_BLOCK = 4096 };
 typedef struct { u64 g[POOL_BLOCK]; u32 next, n; } Pool;
-static Pool pools[32];
+static u64 init_epoch;            /* bumped by every bring-up (legacy blocks bring the runtime up more than once) */
+/* every thread has blocks of its own: the mutex (and the engine) is only needed when one runs out, once per 4096 guids */
+static TLS Pool *pools; static TLS u64 pools_epoch;
 static u64 pool_take(u32 kind) {
-    LOCK();
+    if (!pools || pools_epoch != init_epoch) { /* (a new bring-up is a new engine: its guids start over) */
+        if (!pools) pools = xrealloc(NULL, 32 * sizeof *pools);
+        memset(pools, 0, 32 * sizeof *pools); pools_epoch = init_epoch;
+    }
     Pool *p = &pools[kind];
-    if (p->next == p->n) { CHK(ocrgpu_guid_reserve(G, kind, POOL_BLOCK, p->g, OCRGPU_HOST)); p->next = 0; p->n = POOL_BLOCK; }
-    const u64 g = p->g[p->next++];
-    UNLOCK();
-    return g;
+    if (p->next == p->n) { LOCK(); CHK(ocrgpu_guid_reserve(G, kind, POOL_BLOCK, p->g, OCRGPU_HOST)); UNLOCK(); p->next = 0; p->n = POOL_BLOCK; }
+    return p->g[p->next++];
 }
 
 /* ---- templates and tasks (host metadata: what ocrTaskTemplateHc_t / ocrTaskHc_t keep for taskExecute) ------- */
@@ -88,7 +91,21 @@ typedef struct {
     u64 creator;       /* serial of the body that created it (its check-in is issued when that body returns) */
 } Task;
 static Template *tpls; static size_t n_tpl, cap_tpl;
-static Task *tasks; static size_t n_task, cap_task;
+/* the task table is a list of fixed chunks that never move: a body reads and fills its entries without a lock while other
+ * bodies append theirs (indices come from one atomic counter; a new chunk is entered under the mutex) */
+enum { TASK_CHUNK_BITS = 16, TASK_CHUNKS = 1 << 16 };
+static Task *task_chunk[TASK_CHUNKS]; static size_t n_task;
+static Task *task_at(size_t i) { return &task_chunk[i >> TASK_CHUNK_BITS][i & ((1u << TASK_CHUNK_BITS) - 1)]; }
+static size_t task_new(void) {
+    const size_t i = __sync_fetch_and_add(&n_task, 1), c = i >> TASK_CHUNK_BITS;
+    if (c >= TASK_CHUNKS) die("more than 2^32 EDTs");
+    if (!__atomic_load_n(&task_chunk[c], __ATOMIC_ACQUIRE)) {
+        LOCK();
+        if (!task_chunk[c]) { Task *t = calloc((size_t)1 << TASK_CHUNK_BITS, sizeof *t); if (!t) die("out of host memory"); __atomic_store_n(&task_chunk[c], t, __ATOMIC_RELEASE); }
+        UNLOCK();
+    }
+    return i;
+}
 #define KIND_TEMPLATE 4u /* OCR_GUID_EDT_TEMPLATE (ocr-guid-kind.h:24); never enters the engine */
 static u64 tpl_guid(size_t i) { return ((u64)KIND_TEMPLATE << 49) | (u64)(i + 1); }
 
@@ -135,14 +152,15 @@ static TLS Touched *touched; static TLS size_t n_touched, cap_touched;   /* even
 static TLS Task *cur_task;            /* EDT whose body is running (NULL while mainEdt runs) */
 static TLS u64 cur_scope;             /* latch of the finish scope children are created in   */
 static TLS u32 pending_checkins;      /* children created in cur_scope by this body: INCRs issued when the body returns */
-static TLS u64 cur_body;          /* serial of the running body (Task.creator of what it creates) */
-static u64 body_serial;
+static TLS u64 cur_body;          /* serial of the running body (Task.creator of what it creates): thread number << 40 | count */
+static TLS u64 body_serial, thread_no; static u64 n_threads_seen;
 
-static u64 init_epoch;            /* bumped by every bring-up (legacy blocks bring the runtime up more than once) */
 static void els_reset(void);
 static void body_begin(Task *t) {
     els_reset();
-    cur_round = 0; cur_cls = -1; n_touched = 0; cur_task = t; pending_checkins = 0; cur_body = __sync_add_and_fetch(&body_serial, 1);
+    cur_round = 0; cur_cls = -1; n_touched = 0; cur_task = t; pending_checkins = 0;
+    if (!thread_no) thread_no = __sync_add_and_fetch(&n_threads_seen, 1);
+    cur_body = (thread_no << 40) | ++body_serial;
     cur_scope = t ? (t->own_latch ? t->own_latch : t->scope_latch) : 0;
 }
 static Op *emit(int cls) {
@@ -283,6 +301,7 @@ static void flush(void) {
             break;
         case C_DB_CREATE: /* value = host pointer, tag = guid: what ocrgpu_pop_ready hands back as depv */
             for (size_t k = 0; k < n; ++k) { bu64[0][k] = o[k].b; bu64[1][k] = o[k].a; bu64[2][k] = o[k].a; }
+            for (size_t k = 0; k < n; ++k) dbmap_put(o[k].a, (void *)(uintptr_t)o[k].b); /* guid -> payload, for ocrDbDestroy (entered here, by the one thread that flushes) */
             CHK(ocrgpu_db_create(G, n, bu64[0], bu64[1], bu64[2], OCRGPU_HOST | OCRGPU_GUIDS_GIVEN));
             break;
         case C_EDT_CREATE:
@@ -518,7 +537,6 @@ u8 ocrDbCreate(ocrGuid_t *db, void **addr, u64 len, u16 flags, ocrHint_t *hint, 
     if (!p) return OCR_ENOMEM;
     Op *o = emit(C_DB_CREATE);
     o->a = lg ? lg : pool_take(OCRGPU_KIND_DB); o->b = (u64)(uintptr_t)p;
-    LOCK(); dbmap_put(o->a, p); UNLOCK();
     db->guid = (intptr_t)o->a; *addr = (flags & DB_PROP_NO_ACQUIRE) ? NULL : p; /* ocr-db.h:60-64 */
     return 0;
 }
@@ -540,8 +558,9 @@ u8 ocrEdtTemplateDestroy(ocrGuid_t guid) { (void)guid; return 0; }
 u8 ocrEdtDestroy(ocrGuid_t guid) {
     LOCK();
     for (size_t i = n_task; i-- > 0;) {
-        Task *t = &tasks[i];
-        if (t->guid != (u64)guid.guid) continue;
+        if (!task_chunk[i >> TASK_CHUNK_BITS]) continue;
+        Task *t = task_at(i);
+        if (t->guid != (u64)guid.guid) continue; /* (an entry another body is still filling has guid 0 or a stale one: not ours) */
         if (t->ran || t->destroyed) { UNLOCK(); return 0; }
         t->destroyed = 1;
         const u64 latch = t->scope_latch; const int mine = t->creator == cur_body;
@@ -594,6 +613,8 @@ u8 ocrEdtCreate(ocrGuid_t *guid, ocrGuid_t tplGuid, u32 paramc, u64 *paramv, u32
         t->own_latch = pool_take(OCRGPU_KIND_EVT_LATCH);
         Op *l = emit(C_EVT_CREATE); l->a = t->own_latch; l->slot = OCREVT_LATCH; l->arg = 1;
     }
+    const size_t ti = task_new();
+    *task_at(ti) = nt;
     Op *o = emit(C_EDT_CREATE);
     o->a = t->guid; o->b = own_evt ? 0 : t->outevt; o->c = (u64)ti; o->slot = depc;
     if (finish) {
@@ -645,6 +666,9 @@ static u64 n_levels, n_bodies;
  * (OCRGPU_F_LOCKABLE_DB); the EDTs whose bodies ran since the last refill give their datablocks back before the next step */
 static int g_lockable; static u64 *rel_g; static size_t rel_n, rel_cap;
 
+enum { MAX_WORKERS = 64, PAR_GRAB = 32 };
+static u64 par_min = 64;          /* OCRSHIM_PAR_MIN: fewest bodies of a level worth waking the workers for */
+static int n_workers = 1, workers_up, in_parallel;   /* worker threads: see run_level_parallel() */
 static int shim_init(void) {
     g_verbose = (int)env_u64("OCRSHIM_VERBOSE", 0);
     ocrgpu_config_t cfg; memset(&cfg, 0, sizeof cfg);
@@ -656,12 +680,13 @@ static int shim_init(void) {
     cfg.location = 0;
     cfg.flags = env_u64("OCRSHIM_NANNY", 1) ? OCRGPU_F_NANNY : 0; /* user programs: report double satisfies (hc-task.c:1243) */
     g_lockable = (int)env_u64("OCRSHIM_LOCKABLE", 0); rel_n = 0;
+    if (!workers_up) { n_workers = (int)env_u64("OCRSHIM_WORKERS", 1); if (n_workers < 1) n_workers = 1; if (n_workers > MAX_WORKERS) n_workers = MAX_WORKERS; }
+    par_min = env_u64("OCRSHIM_PAR_MIN", 64); if (par_min < 2) par_min = 2;
     if (g_lockable) cfg.flags |= OCRGPU_F_LOCKABLE_DB;
     /* a second bring-up in one process (legacy blocks, ocr-legacy.h:74) starts from nothing */
     ++init_epoch;
     g_shutdown = g_exit_code = 0;
     n_task = n_tpl = n_ops = 0; n_touched = 0; n_range = 0; rq_n = rq_pos = 0; n_levels = n_bodies = 0;
-    memset(pools, 0, sizeof pools);
     if (dbmap_cap) { memset(dbmap, 0, dbmap_cap * sizeof *dbmap); dbmap_n = 0; }
     if (labset_cap) { memset(labset, 0, labset_cap * sizeof *labset); memset(labalive, 0, labset_cap); labset_n = 0; }
     room[0] = cap_edt = cfg.max_edt; room[1] = cfg.max_evt; room[2] = cfg.max_db; room[3] = g_max_edges = cfg.max_edges;
@@ -707,16 +732,14 @@ static int refill(void) {
     }
 }
 
-/* taskExecute for the next ready EDT (hc-task.c:1864-2181).  0 = no EDT can run any more */
-static int run_one(void) {
-    if (rq_pos == rq_n && !refill()) return 0;
-    const u64 i = rq_pos++;
+static TLS u64 my_bodies;         /* bodies this thread ran since it last added them to n_bodies */
+/* taskExecute for entry i of the run queue (hc-task.c:1864-2181) */
+static void run_index(u64 i) {
     if (rq_p0[i] >= n_task) die("engine returned an unknown task handle");
     const u64 ti = rq_p0[i];
-    /* the task array may move while the body creates EDTs: work on a copy */
-    Task t = tasks[ti];
-    if (t.destroyed) return 1;
-    tasks[ti].ran = 1;
+    Task t = *task_at(ti); /* a copy: the body's context outlives nothing, and ocrEdtDestroy may mark the entry meanwhile */
+    if (t.destroyed) return;
+    task_at(ti)->ran = 1;
     if (rq_dc[i] != t.depc) die("depc mismatch for task %llu", (unsigned long long)ti);
     /* depv is the body's own: a body that blocks runs other bodies underneath it */
     ocrEdtDep_t small[16], *depv = t.depc <= 16 ? small : xrealloc(NULL, t.depc * sizeof *depv);
@@ -729,12 +752,72 @@ static int run_one(void) {
     --run_depth;
     body_end(&t, (u64)ret.guid);
     if (g_lockable && t.depc) {
+        LOCK();
         if (rel_n == rel_cap) { rel_cap = rel_cap ? 2 * rel_cap : 1024; rel_g = xrealloc(rel_g, 8 * rel_cap); }
         rel_g[rel_n++] = t.guid;
+        UNLOCK();
     }
-    free(tasks[ti].paramv); tasks[ti].paramv = NULL;
+    free(t.paramv); task_at(ti)->paramv = NULL;
     if (depv != small) free(depv);
-    ++n_bodies;
+    ++my_bodies;
+}
+
+/* ---- worker threads (hc-worker.c:52-265: every worker loops get-work -> taskExecute) ----------------------------------
+ * The EDTs ocrgpu_pop_ready hands out together fired in one level: none of them depends on another, so OCRSHIM_WORKERS
+ * threads take them off the run queue with an atomic cursor.  The calls a body makes are deferred into its thread's own
+ * queue; when the queue of the level is empty every worker appends what it collected to the driving thread's queue and
+ * parks; the driving thread then flushes, steps the engine and pops the next level alone, as before.  A level of fewer
+ * than OCRSHIM_PAR_MIN (64) bodies is run by the driving thread without waking anybody (a wake-up costs more than the bodies). */
+static pthread_t worker_tid[MAX_WORKERS];
+static pthread_barrier_t bar_start, bar_end;
+static volatile u64 par_next, par_end;
+static Op *wq_ops[MAX_WORKERS]; static size_t wq_n[MAX_WORKERS];   /* what worker w collected in the level just run */
+static void level_share(int w) {
+    for (;;) { /* PAR_GRAB entries per visit to the shared cursor: short bodies would otherwise spend their time on its cache line */
+        if (g_shutdown) break;
+        const u64 i0 = __sync_fetch_and_add(&par_next, PAR_GRAB);
+        if (i0 >= par_end) break;
+        const u64 i1 = i0 + PAR_GRAB < par_end ? i0 + PAR_GRAB : par_end;
+        for (u64 i = i0; i < i1 && !g_shutdown; ++i) run_index(i);
+    }
+    __sync_fetch_and_add(&n_bodies, my_bodies); my_bodies = 0;
+    if (w) { wq_ops[w] = ops; wq_n[w] = n_ops; n_ops = 0; } /* the driver takes them over once everybody is parked (its own queue is in use until then) */
+}
+static void *worker_main(void *arg) {
+    const int w = (int)(intptr_t)arg;
+    for (;;) {
+        pthread_barrier_wait(&bar_start);
+        level_share(w);
+        pthread_barrier_wait(&bar_end);
+    }
+    return NULL;
+}
+static void run_level_parallel(void) {
+    if (!workers_up) {
+        pthread_barrier_init(&bar_start, NULL, (unsigned)n_workers); pthread_barrier_init(&bar_end, NULL, (unsigned)n_workers);
+        for (int w = 1; w < n_workers; ++w) if (pthread_create(&worker_tid[w], NULL, worker_main, (void *)(intptr_t)w)) die("pthread_create failed");
+        workers_up = 1;
+    }
+    par_next = rq_pos; par_end = rq_n; in_parallel = 1;
+    pthread_barrier_wait(&bar_start);
+    level_share(0);
+    pthread_barrier_wait(&bar_end);
+    in_parallel = 0;
+    for (int w = 1; w < n_workers; ++w) { /* whole bodies, worker by worker, each in the order it ran them */
+        if (!wq_n[w]) continue;
+        while (n_ops + wq_n[w] > cap_ops) { cap_ops = cap_ops ? 2 * cap_ops : 1024; ops = xrealloc(ops, cap_ops * sizeof *ops); }
+        memcpy(ops + n_ops, wq_ops[w], wq_n[w] * sizeof *ops);
+        n_ops += wq_n[w]; wq_n[w] = 0;
+    }
+    rq_pos = rq_n;
+}
+
+/* the next ready EDT (or, with worker threads, the rest of the level).  0 = no EDT can run any more */
+static int run_one(void) {
+    if (rq_pos == rq_n && !refill()) return 0;
+    if (n_workers > 1 && run_depth == 0 && rq_n - rq_pos >= par_min) { run_level_parallel(); return 1; }
+    run_index(rq_pos++);
+    n_bodies += my_bodies; my_bodies = 0;
     return 1;
 }
 
@@ -748,8 +831,8 @@ static int shim_fini(void) {
                 (unsigned long long)st.err[0], (unsigned long long)st.err[1], (unsigned long long)st.err[2], (unsigned long long)st.err[3],
                 (unsigned long long)st.err[4], (unsigned long long)st.err[5], (unsigned long long)st.err[6]);
     if (g_verbose)
-        fprintf(stderr, "ocrshim: reclaims=%llu peak_live_edt<=%llu of max_edt=%llu\n", (unsigned long long)n_reclaims,
-                (unsigned long long)peak_live_edt, (unsigned long long)cap_edt);
+        fprintf(stderr, "ocrshim: reclaims=%llu peak_live_edt<=%llu of max_edt=%llu workers=%d\n", (unsigned long long)n_reclaims,
+                (unsigned long long)peak_live_edt, (unsigned long long)cap_edt, n_workers);
     if (g_verbose)
         fprintf(stderr, "ocrshim: seconds: bodies %.3f | queue sort %.3f | batched C-ABI calls %.3f | ocrgpu_step %.3f | ocrgpu_pop_ready %.3f\n",
                 t_bodies, t_sort, t_calls, t_step, t_pop);
@@ -845,6 +928,7 @@ u8 ocrLegacyBlockProgress(ocrGuid_t evtHandle, ocrGuid_t *guid, void **result, u
     if (g == 0 || g >= (u64)-2 || !(OCRGPU_GUID_KIND(g) & OCRGPU_KIND_EVENT)) return OCR_EINVAL;
     static ocrGuid_t tpl; static int have_tpl; static u64 tpl_epoch;
     if (!have_tpl || tpl_epoch != init_epoch) { ocrEdtTemplateCreate(&tpl, watchEdt, 1, 1); have_tpl = 1; tpl_epoch = init_epoch; }
+    if (in_parallel) die("ocrLegacyBlockProgress from inside an EDT needs OCRSHIM_WORKERS=1 (the waiting body would have to drive the engine while other bodies of its level are running)");
     Watch w = { 0, NULL_GUID_INITIALIZER, NULL };
     u64 pv = (u64)(uintptr_t)&w;
     /* the watcher is no child of the caller's finish scope: it must not hold that scope open, nor be counted in it */
