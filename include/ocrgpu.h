@@ -296,6 +296,20 @@ int ocrgpu_comm_fini(ocrgpu_engine_t *e);
 /* the transport alone (grouped ncclSend / ncclRecv on the engine's stream): bytes_per_peer bytes from region p of send_dev to
  * rank p, region p of recv_dev from rank p.  Asynchronous: ocrgpu_sync() or a later call on the engine waits for it. */
 int ocrgpu_comm_alltoall(ocrgpu_engine_t *e, const void *send_dev, void *recv_dev, uint64_t bytes_per_peer);
+/* ---- the comm-platform within ONE node, without a collective: peer windows.  (In place of the same mpi-comm-platform.c calls as
+ *      above -- sendMessage :1055 becomes the sender's kernel STORING its records into the receiver's memory over xGMI, pollMessage
+ *      :287,620-642 becomes the receiver's kernel waiting for one arrival word per source.)  Every partition owns a window of
+ *      fine-grained device memory; ocrgpu_peer_export makes it and fills a 128-byte handle; the caller hands all handles to all
+ *      partitions (any channel: the bytes are plain data); ocrgpu_peer_connect maps the others' windows (hipIpcOpenMemHandle for
+ *      another process, the pointer itself inside one process).  From then on ocrgpu_exchange / ocrgpu_resolve_exchange (and
+ *      their _local forms) move a level's records this way: only the records there are, no RCCL kernel, the wait on the device.
+ *      A source that does not arrive within OCRGPU_PEER_TIMEOUT_MS (default 2000) fails the call (OCRGPU_EHIP); the round is
+ *      then not applied.  All partitions must make the same sequence of exchange calls (as with the communicator).
+ *      handles = n_locations x OCRGPU_PEER_HANDLE_BYTES, in location order, this partition's own included. ------------------- */
+#define OCRGPU_PEER_HANDLE_BYTES 128
+int ocrgpu_peer_export(ocrgpu_engine_t *e, void *handle_out);
+int ocrgpu_peer_connect(ocrgpu_engine_t *e, const void *handles);
+int ocrgpu_peer_fini(ocrgpu_engine_t *e);
 /* One exchange round after ocrgpu_step: headers into the last record slot of every send region {records for that destination,
  * activity = ready-log entries fired + records sent, records sent, satisfies still queued}, the all-to-all of the regions, the
  * apply of what arrived (counts read from the headers ON THE DEVICE), the send counters cleared -- all on the engine's stream,

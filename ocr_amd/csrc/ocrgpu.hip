@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <dlfcn.h>
 #include <time.h>
+#include <unistd.h>
 #include <rccl/rccl.h>   // types only: the library is opened at ocrgpu_comm_init (dlopen), never linked
 #include "ocrgpu.h"
 #include "ocr_opstream.h"
@@ -666,8 +667,23 @@ __device__ __forceinline__ void emit_remote(const Dev &d, u64 guid, u32 slot, u3
 __device__ void emit_remote_raw(const Dev &d, u64 guid, u32 slot, u32 xflags, u64 value, u64 tag) {
     u32 loc = OCRGPU_GUID_LOCATION(guid);
     if (d.send == nullptr || loc >= d.n_loc) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
-    u32 pos = atomicAdd(&d.send_cnt[loc * 32], 1u);
-    if (pos >= d.send_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+    // the lanes of this wavefront that are here together with the same destination take ONE atomic on its counter: a level
+    // of the bench's DAG queues ~5000 records per destination, and one atomic each on a single word took 110 us of the launch
+    const u32 lane = __lane_id();
+    u64 todo = __ballot(1);
+    u32 pos = 0;
+    while (todo) {
+        const u32 leader = (u32)__ffsll((unsigned long long)todo) - 1u;
+        const u32 lloc = __shfl(loc, leader);
+        const u64 same = __ballot(loc == lloc);
+        if (loc == lloc) {
+            u32 base = 0;
+            if (lane == leader) base = atomicAdd(&d.send_cnt[lloc * 32], (u32)__popcll(same));
+            pos = __shfl(base, leader) + (u32)__popcll(same & ((1ull << lane) - 1ull));
+        }
+        todo &= ~same;
+    }
+    if (pos + 1 >= d.send_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // (the last slot of a region is its header)
     d.send[(size_t)loc * d.send_cap + pos] = SendRec{guid, slot, xflags, value, tag};
 }
 
@@ -1586,22 +1602,83 @@ __global__ void k_exchange_headers(Dev d, u32 K) {
 }
 // the receive side of the equal-split exchange, counts taken from the headers on the device (no host read in between):
 // region s of `recs` (stride records, header in the last slot) carries hdr[0] records from partition s
-__global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec *recs, u32 db_floor) {
+__global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec *recs, u32 db_floor, const u32 *skip) {
+    if (skip && *skip) return; // (peer windows: a source did not arrive, the regions are not this round's)
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     const u32 s = (u32)(i / (stride - 1)); const u64 k = i % (stride - 1);
     if (s >= n_src) return;
     const u64 cnt = recs[(u64)s * stride + (stride - 1)].guid; // header word 0
     if (k < cnt) apply_record(d, recs[(u64)s * stride + k], db_floor);
 }
-// sums of the received headers: out[0] = records received, out[1] = activity of all partitions (ready-log entries fired +
-// records sent), out[2] = records sent by all, out[3] = satisfies still queued somewhere
-__global__ void k_exchange_sum_hdr(u32 n_src, u64 stride, const SendRec *recs, u64 *out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u64 a = 0, b = 0, c = 0, q = 0;
-    for (u32 s = 0; s < n_src; ++s) { const u64 *h = (const u64 *)&recs[(u64)s * stride + (stride - 1)]; a += h[0]; b += h[1]; c += h[2]; q += h[3]; }
-    out[0] = a; out[1] = b; out[2] = c; out[3] = q;
-}
 __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
+// reset + header sums + report in ONE launch (they were three): the send counters start the next step at zero, the sums of the
+// received headers and the state / error words go straight into the pinned page the host reads after its one synchronisation
+__global__ void k_exchange_finish(Dev d, u32 K, u32 n_src, u64 stride, const SendRec *recs, u32 *pin) {
+    __shared__ unsigned long long sum[4];
+    const u32 t = threadIdx.x;
+    if (t < 4) sum[t] = 0;
+    __syncthreads();
+    if (t < d.n_loc) d.send_cnt[t * 32] = 0;
+    if (t < n_src) {
+        const u64 *h = (const u64 *)&recs[(u64)t * stride + (stride - 1)];
+        for (u32 k = 0; k < 4; ++k) if (h[k]) atomicAdd(&sum[k], (unsigned long long)h[k]);
+    }
+    __syncthreads();
+    if (t < 4) reinterpret_cast<u64 *>(pin + 33040)[t] = sum[t];
+    const Ctrl *c = d.ctrl;
+    if (t < 32) pin[t] = reinterpret_cast<const u32 *>(&c->state[K & 1])[t];
+    if (t < 8) pin[33020 + t] = c->err[t];
+}
+
+// ---- peer windows: the exchange of one node without a collective.  Every partition owns a WINDOW in its GPU's memory (fine-grained,
+//      so that what peers write over xGMI is seen by the kernels that read it): one arrival word per source partition (64-byte
+//      stride), then two sets (round parity) of n_loc receive regions of send_cap records.  Each partition maps every other
+//      partition's window (hipIpcOpenMemHandle across processes, the plain pointer within one) and, per round, a kernel of the
+//      SENDER stores the records it has for p -- only those, plus the header -- into region [parity][me] of p's window and then
+//      p's arrival word [me] = round + 1; a one-workgroup kernel of the RECEIVER waits for all its arrival words (bounded), and the
+//      apply kernel follows it on the stream.  Two parities are enough: a sender starts round r + 2 only after it has seen every
+//      partition's arrival for r + 1, which each of them stored after its own apply of round r (stream order). ----
+#define PEER_PUSH_BLOCKS 4u
+#define PIN_PEER_LATE 33050u
+struct PeerDev { char *const *base; char *mine; u32 me; u32 *cnt; }; // cnt[p] = push workgroups done for p; cnt[1024] = sources late last round
+__device__ __forceinline__ u64 *peer_arrival(char *base, u32 src) { return (u64 *)(base + 64 * (size_t)src); }
+__host__ __device__ __forceinline__ size_t peer_regions_off(u32 n_loc) { return ((64 * (size_t)n_loc + 255) / 256) * 256; }
+__device__ __forceinline__ SendRec *peer_region(char *base, u32 n_loc, u64 cap, u32 parity, u32 src) {
+    return (SendRec *)(base + peer_regions_off(n_loc)) + ((size_t)parity * n_loc + src) * cap;
+}
+__global__ void k_peer_push(Dev d, PeerDev pd, u64 round) {
+    const u32 p = blockIdx.x / PEER_PUSH_BLOCKS, part = blockIdx.x % PEER_PUSH_BLOCKS;
+    u32 cnt = d.send_cnt[p * 32]; if (cnt > d.send_cap - 1) cnt = d.send_cap - 1;
+    const uint4 *src = (const uint4 *)(d.send + (size_t)p * d.send_cap);
+    uint4 *dst = (uint4 *)peer_region(pd.base[p], d.n_loc, d.send_cap, (u32)(round & 1), pd.me);
+    for (u64 i = part * (u64)blockDim.x + threadIdx.x; i < 2 * (u64)cnt; i += PEER_PUSH_BLOCKS * (u64)blockDim.x) dst[i] = src[i];
+    if (part == 0 && threadIdx.x < 2) dst[2 * (u64)(d.send_cap - 1) + threadIdx.x] = src[2 * (u64)(d.send_cap - 1) + threadIdx.x]; // the header (k_exchange_headers)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&pd.cnt[p], 1u) == PEER_PUSH_BLOCKS - 1) { // the last of p's workgroups: everybody's stores are out
+        pd.cnt[p] = 0;
+        __threadfence_system();
+        __hip_atomic_store(peer_arrival(pd.base[p], pd.me), round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// one workgroup, one lane per source; `limit` in ticks of the 100 MHz wall clock.  A source that does not arrive in time is
+// counted, the round's records are NOT applied (k_exchange_apply_hdr's `skip`), and the host call fails with that count.
+__global__ void k_peer_wait(Dev d, PeerDev pd, u64 round, u64 limit, u32 *pin) {
+    __shared__ u32 late;
+    const u32 s = threadIdx.x;
+    if (s == 0) late = 0;
+    __syncthreads();
+    if (s < d.n_loc) {
+        const u64 *f = peer_arrival(pd.mine, s);
+        const u64 t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < round + 1) {
+            if (wall_clock64() - t0 > limit) { atomicAdd(&late, 1u); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+    if (s == 0) { pd.cnt[1024] = late; pin[PIN_PEER_LATE] = late; }
+}
 __global__ void k_exchange_counts(Dev d, u32 *out) { if (threadIdx.x < d.n_loc) { u32 c = d.send_cnt[threadIdx.x * 32]; out[threadIdx.x] = c > d.send_cap ? d.send_cap : c; } }
 
 // SCHED_GET_WORK for EDTs whose bodies run on the host (hcSchedulerHeuristicGetEdt, hc-scheduler-heuristic.c:148-199,
@@ -1920,6 +1997,9 @@ struct ocrgpu_engine {
     u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
     // comm-platform over RCCL (ocrgpu_comm_*): communicator of this partition, receive regions, a small device word block
     void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records; u64 *xsum_dev;
+    // peer windows (ocrgpu_peer_*): my window, the device table of everybody's, what was opened from other processes, the round
+    // counter every partition advances together, the wait limit in wall-clock ticks; hdr_fresh: the step just queued wrote the headers
+    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> *peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; bool peer_on, hdr_fresh;
     u64 *wp; u64 wp_cap, wp_head, wp_tail; // workpile: ring of guids in HBM, indices kept by the (single) caller side
     // reclaimed capacity (ocrgpu_reclaim, ocrgpu_db_destroy): device tables, host mirrors of the free-stack heights and of the
     // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
@@ -2023,6 +2103,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     ocrgpu_engine *e = new ocrgpu_engine();
     e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
     e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0; e->xsum_dev = nullptr;
+    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_opened = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_on = false; e->hdr_fresh = false;
     e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
     memset(&e->rc, 0, sizeof e->rc); e->n_free_edt = e->n_free_evt = e->n_free_db = e->n_held = 0; e->mut_epoch = 0; e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
@@ -2145,6 +2226,7 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
 } }
 #endif
     if (e->comm) (void)ocrgpu_comm_fini(e);
+    (void)ocrgpu_peer_fini(e);
     if (e->recv_buf) (void)hipFree(e->recv_buf);
     if (e->xsum_dev) (void)hipFree(e->xsum_dev);
     for (void *p : e->allocs) (void)hipFree(p);
@@ -2163,7 +2245,7 @@ extern "C" int ocrgpu_set_stream(ocrgpu_engine_t *e, void *s) { if (!e) FAIL(OCR
 extern "C" int ocrgpu_sync(ocrgpu_engine_t *e) { if (!e) FAIL(OCRGPU_EINVAL, "null engine"); HIPCHK(hipStreamSynchronize(e->stream)); return 0; }
 extern "C" int ocrgpu_set_hash_tag_base(ocrgpu_engine_t *e, u64 b) { if (!e) FAIL(OCRGPU_EINVAL, "null engine"); e->d.hash_tag_base = b; return 0; }
 
-#define ENTER(e) do { if (!(e)) FAIL(OCRGPU_EINVAL, "null engine"); HIPCHK(hipSetDevice((e)->device)); stage_reset(e); } while (0)
+#define ENTER(e) do { if (!(e)) FAIL(OCRGPU_EINVAL, "null engine"); HIPCHK(hipSetDevice((e)->device)); stage_reset(e); (e)->hdr_fresh = false; } while (0)
 
 // ---- CSR seal ---------------------------------------------------------------------------------------------
 static int seal(ocrgpu_engine *e) {
@@ -2623,6 +2705,7 @@ extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *
         if (!e->d.send_cnt) FAIL(OCRGPU_EINVAL, "exchange not configured");
         for (u32 l = 0; l < e->d.n_loc; ++l) { u32 c = e->pinned_done[32 + 32 * l]; send_counts_out[l] = c > e->d.send_cap ? e->d.send_cap : c; }
     }
+    e->hdr_fresh = (flags & OCRGPU_STEP_WRITE_HEADERS) != 0;
     return check_fault(e); // the outputs above are filled either way
 }
 
@@ -2860,7 +2943,6 @@ static int exchange_buffers(ocrgpu_engine *e) { // receive regions + the header 
         HIPCHK(hipMalloc((void **)&e->recv_buf, sizeof(SendRec) * need));
         e->recv_cap_records = need;
     }
-    if (!e->xsum_dev) HIPCHK(hipMalloc((void **)&e->xsum_dev, 64));
     return 0;
 }
 extern "C" int ocrgpu_comm_init(ocrgpu_engine_t *e, const void *id128, int rank, int nranks) {
@@ -2904,33 +2986,126 @@ extern "C" int ocrgpu_comm_alltoall(ocrgpu_engine_t *e, const void *send_dev, vo
 // One exchange round, in three stages so that the same protocol runs over RCCL (one engine per process) and over plain
 // device-to-device copies (several partitions in one process: the tests).  xchg_post: headers into the send regions.
 // xchg_land: apply what arrived, clear the send counters, bring back the header sums (the round's ONE synchronisation).
-static int xchg_post(ocrgpu_engine *e) {
-    int r = exchange_buffers(e); if (r) return r;
+static int xchg_post(ocrgpu_engine *e, bool hdr_fresh) {
+    int r = e->peer_on ? 0 : exchange_buffers(e); if (r) return r;
     if (e->d.n_loc > 1024) FAIL(OCRGPU_EINVAL, "more than 1024 locations");
-    k_exchange_headers<<<1, 1024, 0, e->stream>>>(e->d, e->launch_index);
+    if (!hdr_fresh) k_exchange_headers<<<1, 1024, 0, e->stream>>>(e->d, e->launch_index); // (a step with OCRGPU_STEP_WRITE_HEADERS has just done it)
     HIPCHK(hipGetLastError());
     return 0;
 }
-static int xchg_land(ocrgpu_engine *e, u64 *out4) {
+static int xchg_land(ocrgpu_engine *e, const SendRec *recs, const u32 *skip, u64 *out4) {
     Dev &d = e->d;
     const u64 n = (u64)d.n_loc * (d.send_cap - 1);
-    k_exchange_apply_hdr<<<nblk(n), 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, e->recv_buf, e->n_db);
-    k_exchange_reset<<<1, 1024, 0, e->stream>>>(d);
-    k_exchange_sum_hdr<<<1, 1, 0, e->stream>>>(d.n_loc, d.send_cap, e->recv_buf, e->xsum_dev);
+    k_exchange_apply_hdr<<<nblk(n), 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, recs, e->n_db, skip);
     // the header sums, the state the last step ended in and the error counters ride on the same synchronisation (step_ahead does not poll)
-    k_report<<<1, 64, 0, e->stream>>>(d, e->launch_index, RP_XSUM | RP_STATE | RP_ERR, e->pinned_dev, e->xsum_dev);
+    k_exchange_finish<<<1, 1024, 0, e->stream>>>(d, e->launch_index, d.n_loc, d.send_cap, recs, e->pinned_dev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     memcpy(out4, e->pinned_done + 33040, 32);
     return 0;
 }
-extern "C" int ocrgpu_exchange(ocrgpu_engine_t *e, u64 *records_in_out, u64 *activity_out, u64 *sent_out, u64 *queued_out) {
+
+// ---- peer windows, host side (the kernels and the protocol: k_peer_push above) ----
+struct PeerHandle { hipIpcMemHandle_t ipc; u64 bytes; u32 n_loc, send_cap, location, pid; u64 local_ptr; s32 device; u32 pad[5]; };
+static_assert(sizeof(PeerHandle) <= OCRGPU_PEER_HANDLE_BYTES, "handle size");
+extern "C" int ocrgpu_peer_export(ocrgpu_engine_t *e, void *handle_out) {
     ENTER(e);
-    if (!e->comm) FAIL(OCRGPU_EINVAL, "no communicator (ocrgpu_comm_init)");
-    int r = xchg_post(e); if (r) return r;
-    if ((r = ocrgpu_comm_alltoall(e, e->d.send, e->recv_buf, sizeof(SendRec) * (u64)e->d.send_cap))) return r;
-    u64 h[4];
-    if ((r = xchg_land(e, h))) return r;
+    if (!handle_out) FAIL(OCRGPU_EINVAL, "null handle");
+    Dev &d = e->d;
+    if (!d.send_cnt || !d.send || d.send_cap < 2) FAIL(OCRGPU_EINVAL, "exchange not configured (ocrgpu_exchange_config first)");
+    if (e->peer_on) FAIL(OCRGPU_EINVAL, "this engine's window is already connected");
+    const size_t bytes = peer_regions_off(d.n_loc) + sizeof(SendRec) * 2 * (size_t)d.n_loc * d.send_cap;
+    if (!e->peer_win) {
+        HIPCHK(hipExtMallocWithFlags((void **)&e->peer_win, bytes, hipDeviceMallocFinegrained));
+        e->peer_win_bytes = bytes;
+        HIPCHK(hipMemset(e->peer_win, 0, bytes)); // arrival words start at 0 = nothing arrived; done before anybody can hold the handle
+        HIPCHK(hipDeviceSynchronize());
+    } else if (e->peer_win_bytes != bytes) FAIL(OCRGPU_EINVAL, "the exchange was reconfigured after ocrgpu_peer_export");
+    PeerHandle h; memset(&h, 0, sizeof h);
+    h.bytes = bytes; h.n_loc = d.n_loc; h.send_cap = d.send_cap; h.location = e->cfg.location; h.pid = (u32)getpid(); h.local_ptr = (u64)(uintptr_t)e->peer_win; h.device = e->device;
+    hipError_t er = hipIpcGetMemHandle(&h.ipc, e->peer_win); // (a group inside one process never opens it: not fatal here)
+    if (er != hipSuccess) { (void)hipGetLastError(); memset(&h.ipc, 0, sizeof h.ipc); h.pad[0] = 1u; }
+    memset(handle_out, 0, OCRGPU_PEER_HANDLE_BYTES); memcpy(handle_out, &h, sizeof h);
+    return 0;
+}
+extern "C" int ocrgpu_peer_connect(ocrgpu_engine_t *e, const void *handles) {
+    ENTER(e);
+    if (!handles) FAIL(OCRGPU_EINVAL, "null handles");
+    if (!e->peer_win) FAIL(OCRGPU_EINVAL, "ocrgpu_peer_export first");
+    if (e->peer_on) FAIL(OCRGPU_EINVAL, "already connected");
+    Dev &d = e->d;
+    std::vector<char *> base(d.n_loc, nullptr);
+    std::vector<void *> *opened = new std::vector<void *>();
+    auto undo = [&]() { for (void *q : *opened) (void)hipIpcCloseMemHandle(q); delete opened; };
+    for (u32 p = 0; p < d.n_loc; ++p) {
+        PeerHandle h; memcpy(&h, (const char *)handles + (size_t)p * OCRGPU_PEER_HANDLE_BYTES, sizeof h);
+        if (h.n_loc != d.n_loc || h.send_cap != d.send_cap || h.location != p || h.bytes != e->peer_win_bytes) {
+            undo(); FAIL(OCRGPU_EINVAL, "handle %u is of location %u of %u with regions of %u records: not this partition's shape", p, h.location, h.n_loc, h.send_cap);
+        }
+        if (p == e->cfg.location) { base[p] = e->peer_win; continue; }
+        if (h.pid == (u32)getpid()) { // a partition of this same process: its pointer is good here
+            if (h.device != e->device) { hipError_t er = hipDeviceEnablePeerAccess(h.device, 0); if (er != hipSuccess && er != hipErrorPeerAccessAlreadyEnabled) { undo(); FAIL(OCRGPU_EHIP, "no peer access from device %d to %d: %s", e->device, h.device, hipGetErrorString(er)); } (void)hipGetLastError(); }
+            base[p] = (char *)(uintptr_t)h.local_ptr; continue;
+        }
+        if (h.pad[0]) { undo(); FAIL(OCRGPU_ENOTSUP, "location %u could not export its window to other processes (hipIpcGetMemHandle failed there)", p); }
+        void *q = nullptr;
+        hipError_t er = hipIpcOpenMemHandle(&q, h.ipc, hipIpcMemLazyEnablePeerAccess);
+        if (er != hipSuccess) { (void)hipGetLastError(); undo(); FAIL(OCRGPU_EHIP, "hipIpcOpenMemHandle of location %u's window: %s", p, hipGetErrorString(er)); }
+        opened->push_back(q); base[p] = (char *)q;
+    }
+    if (!e->peer_base_dev) { int r = dalloc(e, (void **)&e->peer_base_dev, 8 * 1024); if (r) { undo(); return r; } }
+    if (!e->peer_cnt) { int r = dalloc(e, (void **)&e->peer_cnt, 4 * 1032); if (r) { undo(); return r; } }
+    HIPCHK(hipMemcpyAsync(e->peer_base_dev, base.data(), 8 * (size_t)d.n_loc, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const char *ms = getenv("OCRGPU_PEER_TIMEOUT_MS");
+    e->peer_limit = 100000ull * (u64)(ms && atoi(ms) > 0 ? atoi(ms) : 2000); // 100 MHz ticks
+    e->peer_opened = opened; e->peer_round = 0; e->peer_on = true;
+    return 0;
+}
+extern "C" int ocrgpu_peer_fini(ocrgpu_engine_t *e) {
+    if (!e) FAIL(OCRGPU_EINVAL, "null engine");
+    if (!e->peer_win && !e->peer_on) return 0;
+    (void)hipSetDevice(e->device); (void)hipStreamSynchronize(e->stream);
+    if (e->peer_opened) { for (void *q : *e->peer_opened) (void)hipIpcCloseMemHandle(q); delete e->peer_opened; e->peer_opened = nullptr; }
+    if (e->peer_win) { (void)hipFree(e->peer_win); e->peer_win = nullptr; }
+    e->peer_on = false;
+    return 0;
+}
+// one round over the windows for the partitions of this process (1 with one process per GPU): every push is queued before any
+// wait, so partitions that share a hardware queue cannot wait on a push that sits behind them
+static int peer_exchange(ocrgpu_engine **g, u32 n, const bool *fresh, u64 *h) {
+    for (u32 i = 0; i < n; ++i) {
+        ocrgpu_engine *e = g[i]; Dev &d = e->d;
+        HIPCHK(hipSetDevice(e->device));
+        int r = xchg_post(e, fresh[i]); if (r) return r;
+        const PeerDev pd{e->peer_base_dev, e->peer_win, e->cfg.location, e->peer_cnt};
+        k_peer_push<<<d.n_loc * PEER_PUSH_BLOCKS, 256, 0, e->stream>>>(d, pd, e->peer_round);
+        HIPCHK(hipGetLastError());
+    }
+    for (u32 i = 0; i < n; ++i) {
+        ocrgpu_engine *e = g[i]; Dev &d = e->d;
+        HIPCHK(hipSetDevice(e->device));
+        const PeerDev pd{e->peer_base_dev, e->peer_win, e->cfg.location, e->peer_cnt};
+        k_peer_wait<<<1, 1024, 0, e->stream>>>(d, pd, e->peer_round, e->peer_limit, e->pinned_dev);
+        const SendRec *recs = (const SendRec *)(e->peer_win + peer_regions_off(d.n_loc)) + (size_t)(e->peer_round & 1) * d.n_loc * d.send_cap;
+        e->peer_round++;
+        int r = xchg_land(e, recs, e->peer_cnt + 1024, h); if (r) return r;
+        if (e->pinned_done[PIN_PEER_LATE]) FAIL(OCRGPU_EHIP, "peer windows: %u of %u partitions did not arrive at location %u within the limit (OCRGPU_PEER_TIMEOUT_MS); "
+                                               "the round was not applied and the run cannot continue", e->pinned_done[PIN_PEER_LATE], d.n_loc, e->cfg.location);
+    }
+    return 0;
+}
+extern "C" int ocrgpu_exchange(ocrgpu_engine_t *e, u64 *records_in_out, u64 *activity_out, u64 *sent_out, u64 *queued_out) {
+    const bool fresh = e && e->hdr_fresh;
+    ENTER(e);
+    if (!e->comm && !e->peer_on) FAIL(OCRGPU_EINVAL, "no transport (ocrgpu_comm_init or ocrgpu_peer_connect)");
+    u64 h[4]; int r;
+    if (e->peer_on) { if ((r = peer_exchange(&e, 1, &fresh, h))) return r; }
+    else {
+        if ((r = xchg_post(e, fresh))) return r;
+        if ((r = ocrgpu_comm_alltoall(e, e->d.send, e->recv_buf, sizeof(SendRec) * (u64)e->d.send_cap))) return r;
+        if ((r = xchg_land(e, e->recv_buf, nullptr, h))) return r;
+    }
     if (records_in_out) *records_in_out = h[0];
     if (activity_out) *activity_out = h[1];
     if (sent_out) *sent_out = h[2];
@@ -2942,8 +3117,20 @@ extern "C" int ocrgpu_exchange_local(ocrgpu_engine_t **engines, u32 n, u64 *acti
     for (u32 i = 0; i < n; ++i) {
         if (!engines[i] || engines[i]->d.n_loc != n || engines[i]->cfg.location != i || engines[i]->d.send_cap != engines[0]->d.send_cap ||
             engines[i]->device != engines[0]->device) FAIL(OCRGPU_EINVAL, "engine %u: the group must be locations 0..n-1 of one n-way partition on one device, equal regions", i);
+    }
+    bool fresh[1024]; u32 n_peer = 0;
+    for (u32 i = 0; i < n; ++i) { fresh[i] = engines[i]->hdr_fresh; engines[i]->hdr_fresh = false; n_peer += engines[i]->peer_on ? 1u : 0u; }
+    if (n_peer) { // the group is connected by windows: the same protocol as between processes
+        if (n_peer != n) FAIL(OCRGPU_EINVAL, "some engines of the group are connected by peer windows, some are not");
+        u64 h[4]; int r = peer_exchange(engines, n, fresh, h); if (r) return r;
+        if (activity_out) *activity_out = h[1];
+        if (sent_out) *sent_out = h[2];
+        if (queued_out) *queued_out = h[3];
+        return 0;
+    }
+    for (u32 i = 0; i < n; ++i) {
         HIPCHK(hipSetDevice(engines[i]->device));
-        int r = xchg_post(engines[i]); if (r) return r;
+        int r = xchg_post(engines[i], fresh[i]); if (r) return r;
     }
     for (u32 i = 0; i < n; ++i) HIPCHK(hipStreamSynchronize(engines[i]->stream)); // the copies below read every engine's regions
     const size_t reg = sizeof(SendRec) * (size_t)engines[0]->d.send_cap;
@@ -2953,7 +3140,7 @@ extern "C" int ocrgpu_exchange_local(ocrgpu_engine_t **engines, u32 n, u64 *acti
                                   hipMemcpyDeviceToDevice, engines[dst]->stream));
     for (u32 i = 0; i < n; ++i) HIPCHK(hipStreamSynchronize(engines[i]->stream)); // (the engines may sit on different streams)
     u64 h[4] = {0, 0, 0, 0};
-    for (u32 i = 0; i < n; ++i) { int r = xchg_land(engines[i], h); if (r) return r; }
+    for (u32 i = 0; i < n; ++i) { int r = xchg_land(engines[i], engines[i]->recv_buf, nullptr, h); if (r) return r; }
     if (activity_out) *activity_out = h[1];
     if (sent_out) *sent_out = h[2];
     if (queued_out) *queued_out = h[3];
@@ -2987,6 +3174,7 @@ static int step_ahead(ocrgpu_engine *e, u32 fire, u32 flags, u32 n_launch) {
     if (d.n_loc <= 1) { k_owed_bodies<<<grid, BLK, 0, e->stream>>>(d); k_owed_clear<<<1, 1, 0, e->stream>>>(d); } // (with partitions bodies run before the fan-out: nothing is owed)
     k_exchange_headers<<<1, 1024, 0, e->stream>>>(d, e->launch_index);
     HIPCHK(hipGetLastError());
+    e->hdr_fresh = true;
     return 0;
 }
 static int group_round(ocrgpu_engine **g, u32 n, bool rccl, u32 fire, u32 step_flags, u64 *h, double *tm, int *fault) {
@@ -3036,7 +3224,7 @@ static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags
 }
 extern "C" int ocrgpu_resolve_exchange(ocrgpu_engine_t *e, u32 flags, u64 *levels_out) {
     if (!e) FAIL(OCRGPU_EINVAL, "null engine");
-    if (!e->comm) FAIL(OCRGPU_EINVAL, "no communicator (ocrgpu_comm_init)");
+    if (!e->comm && !e->peer_on) FAIL(OCRGPU_EINVAL, "no transport (ocrgpu_comm_init or ocrgpu_peer_connect)");
     return resolve_exchange_group(&e, 1, true, flags, levels_out);
 }
 extern "C" int ocrgpu_resolve_exchange_local(ocrgpu_engine_t **engines, u32 n, u32 flags, u64 *levels_out) {

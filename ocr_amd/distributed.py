@@ -350,6 +350,21 @@ def resolve_lockstep_c(parts, no_cascade=False):
     return resolve_exchange_local([p.eng for p in parts], no_cascade=no_cascade)
 
 
+def connect_peer_windows(parts):
+    """The partitions of ONE process joined by peer windows (ocrgpu_peer_export / ocrgpu_peer_connect): from here on
+    resolve_lockstep_c and the engines' exchange run the protocol that one process per GPU runs across processes."""
+    handles = [p.eng.peer_export() for p in parts]
+    for p in parts:
+        p.eng.peer_connect(handles)
+
+
+def connect_peer_windows_dist(part, dist, group=None):
+    """One partition per process: the window handles travel over the process group (plain bytes, any backend will do)."""
+    handles = [None] * dist.get_world_size(group)
+    dist.all_gather_object(handles, part.eng.peer_export(), group=group)
+    part.eng.peer_connect(handles)
+
+
 HOST_GROUP = None   # set to a gloo group to route every collective of the exchange through host memory
 DEV_GROUP = None    # set to an RCCL ("nccl") group to keep the exchange on the GPUs when the default group is a gloo one
 

@@ -75,7 +75,9 @@ EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error
            "ocrgpu_read_events", "ocrgpu_read_dbs", "ocrgpu_read_fired", "ocrgpu_get_stats",
            "ocrgpu_comm_get_unique_id", "ocrgpu_comm_init", "ocrgpu_comm_fini", "ocrgpu_comm_alltoall", "ocrgpu_exchange",
            "ocrgpu_exchange_local", "ocrgpu_resolve_exchange", "ocrgpu_resolve_exchange_local", "ocrgpu_workpile_push",
-           "ocrgpu_workpile_pop", "ocrgpu_db_destroy", "ocrgpu_reclaim"]
+           "ocrgpu_workpile_pop", "ocrgpu_db_destroy", "ocrgpu_reclaim", "ocrgpu_peer_export", "ocrgpu_peer_connect",
+           "ocrgpu_peer_fini"]
+PEER_HANDLE_BYTES = 128
 RX_NO_CASCADE = 1
 WP_PUSH, WP_PUSHBACK, WP_POP, WP_STEAL = 0, 1, 0, 1
 
@@ -333,6 +335,22 @@ class Engine:
 
     def comm_fini(self):
         self._chk(self.lib.ocrgpu_comm_fini(self.h))
+
+    # ---- peer windows: the exchange of one node without a collective (ocrgpu_peer_*) ----
+    def peer_export(self) -> bytes:
+        """Make this partition's window (exchange_config comes first); the 128-byte handle goes to every partition."""
+        buf = C.create_string_buffer(PEER_HANDLE_BYTES)
+        self._chk(self.lib.ocrgpu_peer_export(self.h, buf))
+        return buf.raw
+
+    def peer_connect(self, handles):
+        """handles: the handles of ALL partitions in location order (a list of bytes or one bytes object)."""
+        raw = b"".join(handles) if isinstance(handles, (list, tuple)) else bytes(handles)
+        buf = C.create_string_buffer(raw, len(raw))
+        self._chk(self.lib.ocrgpu_peer_connect(self.h, buf))
+
+    def peer_fini(self):
+        self._chk(self.lib.ocrgpu_peer_fini(self.h))
 
     def comm_alltoall(self, send_dev_ptr, recv_dev_ptr, bytes_per_peer):
         self._chk(self.lib.ocrgpu_comm_alltoall(self.h, C.c_void_p(send_dev_ptr), C.c_void_p(recv_dev_ptr), C.c_uint64(bytes_per_peer)))

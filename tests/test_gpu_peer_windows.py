@@ -1,0 +1,156 @@
+"""Peer windows (ocrgpu_peer_export / ocrgpu_peer_connect): the exchange of one node without a collective.  Senders' kernels
+store their records into the receiver's window, the receiver's kernel waits for one arrival word per source; the loop above it
+(ocrgpu_resolve_exchange) is the one the RCCL transport runs.  Exercised (a) with 2-4 partitions in one process (plain pointers
+into each other's windows) against the single-partition oracle on the streams the RCCL-protocol tests use, and (b) with two and
+three PROCESSES sharing this GPU, windows mapped with hipIpcOpenMemHandle -- the path N ranks on N GPUs take."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import streams
+from ocr_amd import distributed as D
+from ocr_amd import engine as E
+from ocr_amd.opstream import layered_dag
+from oracle import ref as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+ALL = {s.name: s for s in streams.all_streams()}
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("name", ["layered_1k", "event_chain", "latch_incr2_decr2", "counted_events", "channel_events", "cholesky_T8",
+                                  "stencil_16x16x10", "counted_after_null_preslot", "sticky_early_and_late", "wide_fanin"])
+def test_windows_in_one_process_are_partition_invariant(name, world):
+    s = ALL[name]
+    parts = D.build_lockstep([D.Partition(s, r, world) for r in range(world)])
+    D.connect_peer_windows(parts)
+    D.resolve_lockstep_c(parts)
+    res = D.gather_result_lockstep(s, parts)
+    errs = [list(p.eng.stats().err) for p in parts]
+    for p in parts:
+        p.eng.close()
+    assert all(sum(e) == 0 for e in errs), errs
+    assert res.diff(O.run_restatement(s)) == []
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_windows_one_exchange_per_level_rearmed(world):
+    from ocr_amd.workloads import LayeredPartition
+    n, width = 60_000, 1500
+    ref = O.run_restatement(layered_dag(n, width))
+    parts = [LayeredPartition(n, width, r, world, allreduce_sum=None) for r in range(world)]
+    total_leaves = sum(len(p.leaves) for p in parts)
+    for p in parts:
+        p.n_leaves = total_leaves
+        p.build()
+    D.connect_peer_windows(parts)
+    D._lockstep_exchange(parts)
+    for p in parts:
+        p.eng.snapshot()
+    for rep in range(2):
+        for p in parts:
+            p.eng.restore()
+        parts[0].satisfy_start()
+        levels = D.resolve_lockstep_c(parts, no_cascade=True)
+        assert levels == int(ref.level.max()) + 1
+        for p in parts:
+            assert sum(p.eng.stats().err) == 0, list(p.eng.stats().err)
+            lv, val = p.check()
+            ids = np.r_[p.mine, n] if p.rank == 0 else p.mine
+            assert np.array_equal(lv, ref.level[ids]) and np.array_equal(val, ref.val[ids])
+    for p in parts:
+        p.eng.close()
+
+
+def test_a_partition_that_does_not_arrive_fails_the_round(monkeypatch):
+    """two partitions connected, only one of them exchanges: its wait gives up after OCRGPU_PEER_TIMEOUT_MS and the call fails"""
+    monkeypatch.setenv("OCRGPU_PEER_TIMEOUT_MS", "50")
+    s = ALL["layered_1k"]
+    parts = [D.Partition(s, r, 2) for r in range(2)]
+    D.connect_peer_windows(parts)
+    with pytest.raises(E.OcrGpuError, match="did not arrive"):
+        parts[0].eng.exchange()
+    for p in parts:
+        p.eng.close()
+
+
+def test_handles_of_another_shape_are_refused():
+    s = ALL["layered_1k"]
+    a, b = D.Partition(s, 0, 2), D.Partition(s, 1, 2)
+    ha, hb = a.eng.peer_export(), b.eng.peer_export()
+    with pytest.raises(E.OcrGpuError):
+        a.eng.peer_connect([hb, ha])              # location order
+    with pytest.raises(E.OcrGpuError):
+        a.eng.exchange()                          # no transport yet
+    a.eng.peer_connect([ha, hb])
+    with pytest.raises(E.OcrGpuError):
+        a.eng.peer_connect([ha, hb])              # once
+    a.eng.close()
+    b.eng.close()
+
+
+def _worker(rank, world, port, n, width, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ocr_amd import distributed as DD
+    from ocr_amd.workloads import LayeredPartition
+
+    def allreduce_sum(x):
+        t = torch.tensor([int(x)], dtype=torch.int64)
+        dist.all_reduce(t)
+        return int(t.item())
+
+    out = None
+    try:
+        part = LayeredPartition(n, width, rank, world, allreduce_sum=allreduce_sum).build()
+        DD.connect_peer_windows_dist(part, dist)
+        rin, act, sent, queued = part.eng.exchange()          # what construction sent across (nothing for this DAG)
+        assert (rin, sent) == (0, 0)
+        part.eng.snapshot()
+        for _ in range(2):
+            part.eng.restore()
+            part.satisfy_start()
+            dist.barrier()
+            levels = part.eng.resolve_exchange(no_cascade=True)
+            lv, val = part.check()
+            ids = np.r_[part.mine, n] if rank == 0 else part.mine
+            out = (rank, ids, lv, val, levels, list(part.eng.stats().err))
+        dist.barrier()
+        part.eng.close()
+    except Exception as ex:  # noqa: BLE001 -- the parent reports it
+        out = (rank, repr(ex))
+    dist.destroy_process_group()
+    q.put(out)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_processes_sharing_one_gpu_windows_over_ipc(world):
+    width = 1200 if world == 3 else 1000
+    n = 36_000 if world == 3 else 40_000
+    ref = O.run_restatement(layered_dag(n, width))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, width, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for res in results:
+        assert len(res) == 6, res
+        rank, ids, lv, val, levels, err = res
+        assert sum(err) == 0
+        assert levels == n // width + 1
+        assert np.array_equal(lv, ref.level[ids]) and np.array_equal(val, ref.val[ids])

@@ -17,7 +17,7 @@ from ocr_amd import engine as E               # noqa: E402
 from ocr_amd.workloads import LayeredPartition  # noqa: E402
 
 
-def run(world, rccl, polled, n=1_000_000, width=10_000):
+def run(world, rccl, polled, n=1_000_000, width=10_000, windows=False):
     if polled:
         os.environ["OCRGPU_RX_POLLED"] = "1"
     else:
@@ -26,14 +26,18 @@ def run(world, rccl, polled, n=1_000_000, width=10_000):
         from ocr_amd.opstream import layered_dag
         part = D.Partition(layered_dag(n, width), 0, 1)
         part.build()
-        part.eng.comm_init(E.comm_get_unique_id(), 0, 1)
+        if windows:
+            D.connect_peer_windows([part])
+        else:
+            part.eng.comm_init(E.comm_get_unique_id(), 0, 1)
         part.eng.sync()
         t0 = time.perf_counter()
         levels = part.eng.resolve_exchange(no_cascade=True)
         dt = time.perf_counter() - t0
-        print(f"world=1 transport=rccl(1 rank) {'polled (2 syncs/level)' if polled else 'queued ahead (1 sync/level)'}: "
+        print(f"world=1 transport={'peer windows' if windows else 'rccl(1 rank)'} {'polled (2 syncs/level)' if polled else 'queued ahead (1 sync/level)'}: "
               f"{levels} levels, {1e6 * dt / levels:.1f} us per level wall, {n} EDTs", flush=True)
-        part.eng.comm_fini()
+        if not windows:
+            part.eng.comm_fini()
         part.eng.close()
         return
     parts = [LayeredPartition(n, width, r, world, allreduce_sum=None) for r in range(world)]
@@ -43,6 +47,8 @@ def run(world, rccl, polled, n=1_000_000, width=10_000):
         p.build()
     if world > 1:
         D._lockstep_exchange(parts)
+    if windows:
+        D.connect_peer_windows(parts)
     for p in parts:
         p.eng.snapshot()
     best = None
@@ -56,13 +62,27 @@ def run(world, rccl, polled, n=1_000_000, width=10_000):
         levels = D.resolve_lockstep_c(parts, no_cascade=True)
         dt = time.perf_counter() - t0
         best = dt if best is None or dt < best else best
-    print(f"world={world} transport={'rccl(1 rank)' if rccl else 'local copies'} {'polled (2 syncs/level)' if polled else 'queued ahead (1 sync/level)'}: "
+    print(f"world={world} transport={'peer windows' if windows else 'rccl(1 rank)' if rccl else 'local copies'} {'polled (2 syncs/level)' if polled else 'queued ahead (1 sync/level)'}: "
           f"{levels} levels, {1e6 * best / levels:.1f} us per level wall, {n * world} EDTs", flush=True)
     for p in parts:
         p.eng.close()
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["rccl"]:       # the one case a kernel trace wants: python tools/dist_timing.py rccl
+        run(1, True, False)
+        sys.exit(0)
+    if sys.argv[1:] == ["windows2"]:
+        run(2, False, False, windows=True)
+        sys.exit(0)
+    if sys.argv[1:] == ["windows"]:
+        run(1, True, False, windows=True)
+        run(2, False, False, windows=True)
+        run(4, False, False, windows=True)
+        sys.exit(0)
     for world, rccl in ((1, True), (2, False)):
         for polled in (True, False):
             run(world, rccl, polled)
+    run(1, True, False, windows=True)
+    run(2, False, False, windows=True)
+    run(4, False, False, windows=True)
