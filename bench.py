@@ -248,6 +248,35 @@ def c_transport_up(part, torch, dist, rank, world):
     return False
 
 
+def all_ok(torch, dist, ok):
+    v = torch.tensor([1 if ok else 0], dtype=torch.int64)
+    dist.all_reduce(v, op=dist.ReduceOp.MIN)
+    return int(v.item()) == 1
+
+
+def windows_up(part, torch, dist, rank, world):
+    """Join the ranks by peer windows (ocrgpu_peer_export / ocrgpu_peer_connect: every rank maps every other rank's receive
+    window with hipIpcOpenMemHandle; one node, which is what this bench runs on) and run one empty exchange round over them.
+    Used only if EVERY rank got through both stages; otherwise the windows are dropped again and the next transport is tried."""
+    from ocr_amd.distributed import connect_peer_windows_dist
+    why = ""
+    try:
+        connect_peer_windows_dist(part, dist)
+    except Exception as ex:  # noqa: BLE001 -- whatever HIP refuses on this machine
+        why = f"{type(ex).__name__}: {str(ex)[:300]}"
+    if all_ok(torch, dist, not why):
+        try:
+            rin, act, sent, queued = part.eng.exchange()
+            assert (rin, sent) == (0, 0), (rin, sent)
+        except Exception as ex:  # noqa: BLE001
+            why = f"{type(ex).__name__}: {str(ex)[:300]}"
+        if all_ok(torch, dist, not why):
+            return True
+    part.eng.peer_fini()
+    print(f"[bench] rank {rank}: peer windows unusable ({why or 'another rank failed'})", file=sys.stderr)
+    return False
+
+
 def main_partitioned(args, torch, dist, rank, world, local, backend):
     """N > 1: ONE global DAG of world x n_edt EDTs (same layer count, layers world x wider), GUID space partitioned
     round-robin over the ranks; satisfies whose destination lives on another GPU are exchanged per level with an
@@ -269,18 +298,49 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     distributed_exchange(part, dist)             # deliver what construction sent across (nothing for this DAG)
     # the per-level loop and the exchange run in C over libocrgpu's own RCCL communicator (ocrgpu_resolve_exchange); when
     # RCCL cannot come up (a rehearsal with several ranks on one GPU) the same protocol runs from Python over gloo
-    use_c = backend == "nccl" and c_transport_up(part, torch, dist, rank, world)
-    backend = "RCCL, C transport: ocrgpu_resolve_exchange" if use_c else "gloo, host-staged records"
+    # Transports, best first (OCRGPU_BENCH_TRANSPORT = windows | rccl | gloo picks one): peer windows (stores into the
+    # receiver's memory over xGMI, no collective), the RCCL all-to-all, records staged through the host over gloo.
+    want = os.environ.get("OCRGPU_BENCH_TRANSPORT", "auto")
+    transport = "gloo"
+    if want in ("auto", "windows") and windows_up(part, torch, dist, rank, world):
+        transport = "windows"
+    elif want in ("auto", "rccl") and backend == "nccl" and c_transport_up(part, torch, dist, rank, world):
+        transport = "rccl"
     part.eng.snapshot()
     part.eng.sync()
-    build_s = time.time() - t0
+    expect_levels = N // width + 1
 
-    def step():
+    def step(time_steps=False):
         part.eng.restore()
         part.satisfy_start()
-        if use_c:
-            return part.eng.resolve_exchange(no_cascade=True)
+        if transport != "gloo":
+            return part.eng.resolve_exchange(no_cascade=True, time_steps=time_steps)
         return resolve_distributed(part, dist)
+
+    # one untimed resolve proves the transport on the real DAG before anything is timed; a transport that fails it on any
+    # rank (an exception, a wrong level count) is dropped by all ranks together and the next one takes over
+    while transport != "gloo":
+        why = ""
+        try:
+            if os.environ.get("OCRGPU_BENCH_INJECT_FAILURE") == transport and rank == world - 1:
+                raise RuntimeError("injected (tests: the other ranks must time out, and everybody falls back together)")
+            got = step()
+            assert got == expect_levels, f"{got} levels, expected {expect_levels}"
+        except Exception as ex:  # noqa: BLE001
+            why = f"{type(ex).__name__}: {str(ex)[:300]}"
+        if all_ok(torch, dist, not why):
+            break
+        print(f"[bench] rank {rank}: transport {transport} failed its first resolve ({why or 'on another rank'})", file=sys.stderr)
+        if transport == "windows":
+            part.eng.peer_fini()
+            transport = "rccl" if want == "auto" and backend == "nccl" and c_transport_up(part, torch, dist, rank, world) else "gloo"
+        else:
+            part.eng.comm_fini()
+            transport = "gloo"
+    backend = {"windows": "peer windows: records stored into the receiver's memory over xGMI, no collective; C loop ocrgpu_resolve_exchange",
+               "rccl": "all-to-all (RCCL, C transport: ocrgpu_resolve_exchange)",
+               "gloo": "all-to-all (gloo, host-staged records)"}[transport]
+    build_s = time.time() - t0
 
     def fence():
         torch.cuda.synchronize()
@@ -308,6 +368,14 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     n_sat = part.sum_depc_global + 1 + part.n_leaves
     assert edt_sat == part.sum_depc_global + 1, (edt_sat, part.sum_depc_global + 1)
     step_kernel_s = (st.step_kernel_ns - k0) * 1e-9 / args.steps
+    kernel_note = "k_step on rank 0 (HIP events on the engine stream, all launches of one resolve)"
+    if transport != "gloo":
+        # the C loop queues a level's launches ahead without events; one more resolve, outside the timed region, with HIP events
+        # around every level's k_step launches (OCRGPU_RX_TIME_STEPS) gives the kernel time the roofline wants
+        k1 = part.eng.stats().step_kernel_ns
+        step(time_steps=True)
+        step_kernel_s = (part.eng.stats().step_kernel_ns - k1) * 1e-9
+        kernel_note = "k_step on rank 0 (HIP events around every level's launches, one extra resolve after the timed ones)"
     if rank == 0:
         ms = dt / args.steps * 1e3
         alg_bytes = (16 * n_sat + 20 * (N + 1)) / world
@@ -318,14 +386,14 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"layered random DAG, {N} EDTs in {N // width} layers of {width} ({args.n_edt} EDTs per GPU), "
                                    f"depc=1+popcount(6 bits) (mean 4), ONCE output events, HASH bodies, latch+sink; GUID space "
-                                   f"partitioned round-robin over {world} GPUs, cross-partition satisfies by per-level all-to-all ({backend})",
+                                   f"partitioned round-robin over {world} GPUs, cross-partition satisfies exchanged per level by {backend}",
                        "n_edt": N + 1, "n_satisfactions": n_sat, "levels": int(levels),
                        "edts_fired_per_s": (N + 1) / (dt / args.steps), "build_s": round(build_s, 2),
                        "parity": "every EDT fired at the level of its layer on every rank; partition invariance vs the "
                                  "single-partition oracle is proven by tests/test_gpu_partitioned.py and test_gpu_workload_partition.py"},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / step_kernel_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": alg_bytes / step_kernel_s / 1e9 / 8000.0, "traffic": None,
-                         "kernel": "k_step on rank 0 (HIP events on the engine stream, all launches of one resolve)",
+                         "kernel": kernel_note,
                          "alg_bytes_per_resolve": alg_bytes, "kernel_s_per_resolve": step_kernel_s},
         }
         print(json.dumps(out))

@@ -327,6 +327,9 @@ int ocrgpu_exchange_local(ocrgpu_engine_t **engines, uint32_t n, uint64_t *activ
  * waiter chains), so one exchange per level settles it (two host synchronisations per level: the step's, the exchange's).
  * OCRGPU_DIST_TIMING=1 in the environment: location 0 prints where a level's wall time went. */
 #define OCRGPU_RX_NO_CASCADE 1u
+/* OCRGPU_RX_TIME_STEPS (engines made with OCRGPU_F_TIMING): HIP events around every level's k_step launches, summed into
+ * ocrgpu_stats_t.step_kernel_ns.  Two event records per level: for a profiling pass, not for the pass whose wall time is reported. */
+#define OCRGPU_RX_TIME_STEPS 2u
 int ocrgpu_resolve_exchange(ocrgpu_engine_t *e, uint32_t flags, uint64_t *levels_out);
 int ocrgpu_resolve_exchange_local(ocrgpu_engine_t **engines, uint32_t n, uint32_t flags, uint64_t *levels_out);
 

@@ -1167,7 +1167,7 @@ __global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) {
 }
 // End of a run whose last launch was K: fold the run state back into the between-runs view; if the record
 // log is fully consumed, rewind it (keeps q_cap small).
-__global__ void k_end(Dev d, u32 K) {
+__device__ __forceinline__ void end_of_run(const Dev &d, u32 K) {
     Ctrl *c = d.ctrl;
     const State P = c->state[K & 1];
     c->level = P.level; c->r_end = P.r_end; c->n_levels = P.n_levels;
@@ -1178,6 +1178,7 @@ __global__ void k_end(Dev d, u32 K) {
     c->q_begin = P.q_end; c->q_tail = qt;
     if (P.done && P.q_end >= qt) { c->q_begin = 0; c->q_tail = 0; }
 }
+__global__ void k_end(Dev d, u32 K) { end_of_run(d, K); }
 
 // ------------------------------------------------------------------------------------------------
 // construction kernels
@@ -1586,8 +1587,10 @@ __global__ void k_exchange_apply_strided(Dev d, u32 n_src, u64 stride, u32 max_c
     apply_record(d, recs[(u64)s * stride + k], db_floor);
 }
 // OCRGPU_STEP_WRITE_HEADERS: {records for this destination, my activity} in the last record slot of every region
-__global__ void k_exchange_headers(Dev d, u32 K) {
+// (end != 0: the run's k_end rides along on lane 0 -- it folds Ctrl.state[K & 1] into the between-runs words and changes nothing the headers read)
+__global__ void k_exchange_headers(Dev d, u32 K, u32 end = 0) {
     const u32 loc = threadIdx.x;
+    if (end && loc == 0) end_of_run(d, K);
     if (loc >= d.n_loc) return;
     const State *S = &d.ctrl->state[K & 1];
     u64 sent = 0;
@@ -1604,11 +1607,12 @@ __global__ void k_exchange_headers(Dev d, u32 K) {
 // region s of `recs` (stride records, header in the last slot) carries hdr[0] records from partition s
 __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec *recs, u32 db_floor, const u32 *skip) {
     if (skip && *skip) return; // (peer windows: a source did not arrive, the regions are not this round's)
-    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    const u32 s = (u32)(i / (stride - 1)); const u64 k = i % (stride - 1);
+    const u32 per = gridDim.x / n_src; // workgroups per source: the grid is n_src * per, whatever the regions' capacity
+    const u32 s = blockIdx.x / per, part = blockIdx.x % per;
     if (s >= n_src) return;
-    const u64 cnt = recs[(u64)s * stride + (stride - 1)].guid; // header word 0
-    if (k < cnt) apply_record(d, recs[(u64)s * stride + k], db_floor);
+    u64 cnt = recs[(u64)s * stride + (stride - 1)].guid; // header word 0
+    if (cnt > stride - 1) cnt = stride - 1;
+    for (u64 k = part * (u64)blockDim.x + threadIdx.x; k < cnt; k += per * (u64)blockDim.x) apply_record(d, recs[(u64)s * stride + k], db_floor);
 }
 __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
 // reset + header sums + report in ONE launch (they were three): the send counters start the next step at zero, the sums of the
@@ -1638,7 +1642,7 @@ __global__ void k_exchange_finish(Dev d, u32 K, u32 n_src, u64 stride, const Sen
 //      p's arrival word [me] = round + 1; a one-workgroup kernel of the RECEIVER waits for all its arrival words (bounded), and the
 //      apply kernel follows it on the stream.  Two parities are enough: a sender starts round r + 2 only after it has seen every
 //      partition's arrival for r + 1, which each of them stored after its own apply of round r (stream order). ----
-#define PEER_PUSH_BLOCKS 4u
+#define PEER_PUSH_BLOCKS 16u
 #define PIN_PEER_LATE 33050u
 struct PeerDev { char *const *base; char *mine; u32 me; u32 *cnt; }; // cnt[p] = push workgroups done for p; cnt[1024] = sources late last round
 __device__ __forceinline__ u64 *peer_arrival(char *base, u32 src) { return (u64 *)(base + 64 * (size_t)src); }
@@ -1999,7 +2003,7 @@ struct ocrgpu_engine {
     void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records; u64 *xsum_dev;
     // peer windows (ocrgpu_peer_*): my window, the device table of everybody's, what was opened from other processes, the round
     // counter every partition advances together, the wait limit in wall-clock ticks; hdr_fresh: the step just queued wrote the headers
-    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> *peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; bool peer_on, hdr_fresh;
+    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> *peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; bool peer_on, hdr_fresh, ahead_timed;
     u64 *wp; u64 wp_cap, wp_head, wp_tail; // workpile: ring of guids in HBM, indices kept by the (single) caller side
     // reclaimed capacity (ocrgpu_reclaim, ocrgpu_db_destroy): device tables, host mirrors of the free-stack heights and of the
     // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
@@ -2103,7 +2107,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     ocrgpu_engine *e = new ocrgpu_engine();
     e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
     e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0; e->xsum_dev = nullptr;
-    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_opened = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_on = false; e->hdr_fresh = false;
+    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_opened = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false;
     e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
     memset(&e->rc, 0, sizeof e->rc); e->n_free_edt = e->n_free_evt = e->n_free_db = e->n_held = 0; e->mut_epoch = 0; e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
@@ -2995,8 +2999,8 @@ static int xchg_post(ocrgpu_engine *e, bool hdr_fresh) {
 }
 static int xchg_land(ocrgpu_engine *e, const SendRec *recs, const u32 *skip, u64 *out4) {
     Dev &d = e->d;
-    const u64 n = (u64)d.n_loc * (d.send_cap - 1);
-    k_exchange_apply_hdr<<<nblk(n), 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, recs, e->n_db, skip);
+    u32 per = (d.send_cap + 254u) / 256u; if (per > 32u) per = 32u; // workgroups per source region
+    k_exchange_apply_hdr<<<d.n_loc * per, 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, recs, e->n_db, skip);
     // the header sums, the state the last step ended in and the error counters ride on the same synchronisation (step_ahead does not poll)
     k_exchange_finish<<<1, 1024, 0, e->stream>>>(d, e->launch_index, d.n_loc, d.send_cap, recs, e->pinned_dev);
     HIPCHK(hipGetLastError());
@@ -3156,8 +3160,18 @@ static double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t
 // level's events fire, the launch that notices the end), then the headers; whether the step was really over is read back with
 // the exchange's own synchronisation (xchg_land), so a level costs ONE host synchronisation.  A step that was not over says
 // so in its headers ("queued"), which brings every partition back for a settle round, and is finished with polls there.
-static int step_ahead(ocrgpu_engine *e, u32 fire, u32 flags, u32 n_launch) {
+static int ahead_time_flush(ocrgpu_engine *e) { // the k_step launches of the last timed step_ahead, once its events have passed
+    if (!e->ahead_timed) return 0;
+    e->ahead_timed = false;
+    HIPCHK(hipEventSynchronize(e->ev1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->step_ns_total += (u64)(ms * 1e6);
+    return 0;
+}
+static int step_ahead(ocrgpu_engine *e, u32 fire, u32 flags, u32 n_launch, bool timed) {
     ENTER(e);
+    timed = timed && e->have_events;
+    if (timed) { int r0 = ahead_time_flush(e); if (r0) return r0; }
     Dev &d = e->d;
     int r = seal(e); if (r) return r;
     if (!d.send_cnt || d.n_loc > 1024 || d.send_cap < 2) FAIL(OCRGPU_EINVAL, "exchange not configured");
@@ -3166,23 +3180,24 @@ static int step_ahead(ocrgpu_engine *e, u32 fire, u32 flags, u32 n_launch) {
     k_begin<<<1, 1, 0, e->stream>>>(d, K, fire, flags & (OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_DROP_EMPTY_LEVEL));
     const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
     const u32 grid = e->step_grid > MAX_GRID ? MAX_GRID : (e->step_grid ? e->step_grid : 256u);
+    if (timed) HIPCHK(hipEventRecord(e->ev0, e->stream));
     for (u32 k = 0; k < n_launch; ++k, ++K) {
         launch_step(e, grid, K);
     }
+    if (timed) { HIPCHK(hipEventRecord(e->ev1, e->stream)); e->ahead_timed = true; }
     e->launches_total += n_launch; e->launch_index = K - 1;
-    k_end<<<1, 1, 0, e->stream>>>(d, K - 1);
-    if (d.n_loc <= 1) { k_owed_bodies<<<grid, BLK, 0, e->stream>>>(d); k_owed_clear<<<1, 1, 0, e->stream>>>(d); } // (with partitions bodies run before the fan-out: nothing is owed)
-    k_exchange_headers<<<1, 1024, 0, e->stream>>>(d, e->launch_index);
+    if (d.n_loc <= 1) { k_end<<<1, 1, 0, e->stream>>>(d, K - 1); k_owed_bodies<<<grid, BLK, 0, e->stream>>>(d); k_owed_clear<<<1, 1, 0, e->stream>>>(d); } // (with partitions bodies run before the fan-out: nothing is owed)
+    k_exchange_headers<<<1, 1024, 0, e->stream>>>(d, e->launch_index, d.n_loc <= 1 ? 0u : 1u);
     HIPCHK(hipGetLastError());
     e->hdr_fresh = true;
     return 0;
 }
-static int group_round(ocrgpu_engine **g, u32 n, bool rccl, u32 fire, u32 step_flags, u64 *h, double *tm, int *fault) {
+static int group_round(ocrgpu_engine **g, u32 n, bool rccl, u32 fire, u32 step_flags, u64 *h, double *tm, int *fault, bool timed = false, u32 n_fire = 4u) {
     const double t0 = now_s();
     const bool polled = getenv("OCRGPU_RX_POLLED") != nullptr; // the two-synchronisation round of before (A/B, debugging)
     for (u32 i = 0; i < n; ++i) {
         const char *nl = getenv("OCRGPU_RX_LAUNCHES"); // tests: a budget of 1 makes every step run out and take the catch-up path
-        int r = polled ? ocrgpu_step(g[i], fire, step_flags, nullptr, nullptr, nullptr) : step_ahead(g[i], fire, step_flags, nl ? (u32)atoi(nl) : (fire ? 4u : 2u));
+        int r = polled ? ocrgpu_step(g[i], fire, step_flags, nullptr, nullptr, nullptr) : step_ahead(g[i], fire, step_flags, nl ? (u32)atoi(nl) : (fire ? n_fire : 2u), timed);
         if (r == OCRGPU_EFAULT) *fault = r; else if (r) return r;
     }
     const double t1 = now_s();
@@ -3204,17 +3219,20 @@ static int group_round(ocrgpu_engine **g, u32 n, bool rccl, u32 fire, u32 step_f
 static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags, u64 *levels_out) {
     u64 h[4] = {0, 0, 0, 0}, levels = 0;
     double tm[2] = {0, 0}; const bool timing = getenv("OCRGPU_DIST_TIMING") != nullptr;
-    int r, fault = 0;
-    do { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, nullptr, &fault))) return r; } while (h[2] || h[3]); // what the main program sent settles first
+    int r, fault = 0; const bool timed = (flags & OCRGPU_RX_TIME_STEPS) != 0;
+    do { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, nullptr, &fault, timed))) return r; } while (h[2] || h[3]); // what the main program sent settles first
     for (;;) {
-        if ((r = group_round(g, n, rccl, 1u, OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault))) return r;
+        // launches queued for a level: the records that arrived, the level itself, the one that notices the end; one more where
+        // arrivals may fire events that send on (a step that needs more says so and is finished with polls)
+        if ((r = group_round(g, n, rccl, 1u, OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault, timed, (flags & OCRGPU_RX_NO_CASCADE) ? 3u : 4u))) return r;
         u64 act = h[1];
         if (!(flags & OCRGPU_RX_NO_CASCADE) || h[3])
-            while (h[2] || h[3]) { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault))) return r; act += h[1]; }
+            while (h[2] || h[3]) { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault, timed))) return r; act += h[1]; }
         if (act == 0) break; // nobody fired or sent anything: the probe level is dropped below
         ++levels;
     }
     for (u32 i = 0; i < n; ++i) { r = ocrgpu_step(g[i], 0u, OCRGPU_STEP_DROP_EMPTY_LEVEL, nullptr, nullptr, nullptr); if (r == OCRGPU_EFAULT) fault = r; else if (r) return r; }
+    for (u32 i = 0; i < n; ++i) if ((r = ahead_time_flush(g[i]))) return r;
     if (timing && g[0]->cfg.location == 0 && levels)
         fprintf(stderr, "[ocrgpu dist timing] us per level: engine step %.1f | exchange (headers, all-to-all, apply, one sync) %.1f | %llu levels\n",
                 1e6 * tm[0] / (double)(levels + 1), 1e6 * tm[1] / (double)(levels + 1), (unsigned long long)levels);

@@ -79,6 +79,7 @@ EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error
            "ocrgpu_peer_fini"]
 PEER_HANDLE_BYTES = 128
 RX_NO_CASCADE = 1
+RX_TIME_STEPS = 2
 WP_PUSH, WP_PUSHBACK, WP_POP, WP_STEAL = 0, 1, 0, 1
 
 _lib = None
@@ -361,10 +362,11 @@ class Engine:
         self._chk(self.lib.ocrgpu_exchange(self.h, *[C.byref(x) for x in out]))
         return tuple(int(x.value) for x in out)
 
-    def resolve_exchange(self, no_cascade=False):
-        """The worker loop across partitions, in C over RCCL (collective).  Returns the number of levels fired."""
+    def resolve_exchange(self, no_cascade=False, time_steps=False):
+        """The worker loop across partitions, in C over peer windows or RCCL (collective).  Returns the number of levels fired."""
         lv = C.c_uint64()
-        self._chk(self.lib.ocrgpu_resolve_exchange(self.h, C.c_uint32(RX_NO_CASCADE if no_cascade else 0), C.byref(lv)))
+        flags = (RX_NO_CASCADE if no_cascade else 0) | (RX_TIME_STEPS if time_steps else 0)
+        self._chk(self.lib.ocrgpu_resolve_exchange(self.h, C.c_uint32(flags), C.byref(lv)))
         return int(lv.value)
 
     # ---- workpile (ocrWorkpileFcts_t push / pop) ----

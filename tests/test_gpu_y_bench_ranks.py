@@ -1,7 +1,8 @@
 """bench.py's N > 1 path end to end, rehearsed with two ranks on the one GPU of the test box.  `python bench.py --gpus 2`
 with no RANK / WORLD_SIZE set starts its two ranks itself (the command the driver runs); one case goes through
-torch.distributed.run as well.  The RCCL group cannot come up with two ranks on one device (or is not asked for),
-so the exchange runs over gloo with host-staged records -- the same per-level protocol, the same engine calls
+torch.distributed.run as well.  Peer windows (hipIpcOpenMemHandle) work between two processes on one device, so
+the default transport is the one N ranks on N GPUs get; the RCCL group cannot come up with two ranks on one device, so that case
+checks the fall-back to gloo with host-staged records -- the same per-level protocol, the same engine calls
 (ocrgpu_step with engine-written headers, ocrgpu_exchange_apply_strided), and bench.py's own checks (every EDT fired at
 the level of its layer on every rank, counts add up).  Collected late (file name) so that trouble here cannot hide the
 parity tests from a run with -x."""
@@ -23,11 +24,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-# "nccl": the self-test must notice it cannot run and fall back, on every rank
-@pytest.mark.parametrize("backend,launcher", [("gloo", "self"), ("nccl", "self"), ("gloo", "torchrun")])
-def test_bench_two_ranks_on_one_gpu(backend, launcher):
+# transport "auto": peer windows come up (two processes may map each other's windows on one GPU too) and carry the exchange;
+# "rccl" with the nccl backend: the self-test must notice it cannot run with two ranks on one device and fall back to gloo, on
+# every rank; "gloo": records staged through the host
+@pytest.mark.parametrize("backend,launcher,transport", [("gloo", "self", "auto"), ("nccl", "self", "auto"), ("nccl", "self", "rccl"),
+                                                        ("gloo", "self", "gloo"), ("gloo", "torchrun", "auto")])
+def test_bench_two_ranks_on_one_gpu(backend, launcher, transport):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    env.update(OCRGPU_BENCH_BACKEND=backend, MASTER_ADDR="127.0.0.1")
+    env.update(OCRGPU_BENCH_BACKEND=backend, MASTER_ADDR="127.0.0.1", OCRGPU_BENCH_TRANSPORT=transport)
     bench = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-edt", "400000", "--width", "4000"]
     if launcher == "self":       # bench.py spawns its own ranks before it touches the GPU
         cmd = [sys.executable] + bench
@@ -42,10 +46,23 @@ def test_bench_two_ranks_on_one_gpu(backend, launcher):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["config"]["n_edt"] == 2 * 400000 + 1 and 100 <= out["config"]["levels"] <= 103   # 100 layers + latch/sink
     wl = out["config"]["workload"]
-    assert "all-to-all (gloo" in wl or "all-to-all (RCCL" in wl   # one GPU: gloo (RCCL refuses two ranks on one device); more: RCCL may come up
-    if backend == "gloo":
-        assert "all-to-all (gloo" in wl
+    if transport == "auto":
+        assert "peer windows" in wl
+    else:
+        assert "all-to-all (gloo" in wl                          # one GPU: RCCL refuses two ranks on one device
     assert out["roofline"]["frac"] > 0
+
+
+def test_bench_falls_back_when_the_windows_fail_mid_run():
+    """rank 1 drops out of the first resolve over the windows: rank 0's wait gives up (OCRGPU_PEER_TIMEOUT_MS), both ranks drop
+    the windows together and the run completes over the next transport"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(OCRGPU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OCRGPU_BENCH_INJECT_FAILURE="windows", OCRGPU_PEER_TIMEOUT_MS="300")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n-edt", "200000", "--width", "4000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert "all-to-all (gloo" in out["config"]["workload"] and "failed its first resolve" in r.stderr
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
