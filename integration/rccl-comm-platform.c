@@ -77,6 +77,53 @@ static u8 rcclShareUniqueId(u32 location, u8 id[128]) {
     return OCR_EAGAIN; /* the id file never appeared */
 }
 
+/* OCRGPU_COMM_WINDOWS=1 (all locations on one node): peer windows in place of the communicator.  Every location writes its
+ * 128-byte window handle to <OCRGPU_COMM_ID_FILE>.<location> and reads everybody's; then ocrgpu_peer_connect maps the windows */
+static u8 rcclShareWindowHandles(u32 location, u32 nLocations) {
+    const char *path = getenv("OCRGPU_COMM_ID_FILE");
+    if(path == NULL || nLocations > 1024) return OCR_EINVAL;
+    u8 *all = (u8 *)runtimeChunkAlloc((u64)nLocations * OCRGPU_PEER_HANDLE_BYTES, PERSISTENT_CHUNK);
+    char name[600], tmp[640];
+    OCRGPU_ENTER();
+    int rc = ocrgpu_peer_export(ocrgpuBinding.engine, all + (u64)location * OCRGPU_PEER_HANDLE_BYTES);
+    OCRGPU_LEAVE();
+    u8 toReturn = rc == OCRGPU_OK ? 0 : ocrgpuToOcrError(rc);
+    if(toReturn == 0) {
+        snprintf(name, sizeof name, "%s.%u", path, location);
+        snprintf(tmp, sizeof tmp, "%s.tmp", name);
+        FILE *f = fopen(tmp, "wb");
+        if(f == NULL || fwrite(all + (u64)location * OCRGPU_PEER_HANDLE_BYTES, 1, OCRGPU_PEER_HANDLE_BYTES, f) != OCRGPU_PEER_HANDLE_BYTES) toReturn = OCR_EIO;
+        if(f != NULL) fclose(f);
+        if(toReturn == 0 && rename(tmp, name) != 0) toReturn = OCR_EIO;
+    }
+    u32 p;
+    for(p = 0; p < nLocations && toReturn == 0; ++p) {
+        if(p == location) continue;
+        u32 tries; u8 got = 0;
+        snprintf(name, sizeof name, "%s.%u", path, p);
+        for(tries = 0; tries < 6000 && !got; ++tries) {
+            FILE *f = fopen(name, "rb");
+            if(f != NULL) {
+                got = fread(all + (u64)p * OCRGPU_PEER_HANDLE_BYTES, 1, OCRGPU_PEER_HANDLE_BYTES, f) == OCRGPU_PEER_HANDLE_BYTES;
+                fclose(f);
+            }
+            if(!got) usleep(10000);
+        }
+        if(!got) toReturn = OCR_EAGAIN; /* that location's handle never appeared */
+    }
+    if(toReturn == 0) {
+        OCRGPU_ENTER();
+        rc = ocrgpu_peer_connect(ocrgpuBinding.engine, all);
+        OCRGPU_LEAVE();
+        if(rc != OCRGPU_OK) {
+            DPRINTF(DEBUG_LVL_WARN, "RCCL comm-platform, peer windows: %s\n", ocrgpu_last_error());
+            toReturn = ocrgpuToOcrError(rc);
+        }
+    }
+    runtimeChunkFree((u64)all, PERSISTENT_CHUNK);
+    return toReturn;
+}
+
 /* the communicator comes up once the engine exists (the GUID provider makes it at RL_GUID_OK) and goes away before it does:
  * where mpi-comm-platform.c has MPI_Init / the start barrier (:54,1726-1735) and MPI_Finalize (:60) */
 static u8 rcclCommSwitchRunlevel(ocrCommPlatform_t *self, ocrPolicyDomain_t *PD, ocrRunlevel_t runlevel, phase_t phase, u32 properties,
@@ -108,6 +155,8 @@ static u8 rcclCommSwitchRunlevel(ocrCommPlatform_t *self, ocrPolicyDomain_t *PD,
             int rc = ocrgpu_exchange_config(ocrgpuBinding.engine, ocrgpuBinding.nLocations, NULL, rself->recordsPerDest, rself->maxRemoteDsts);
             OCRGPU_LEAVE();
             if(rc != OCRGPU_OK) return ocrgpuToOcrError(rc);
+            if(getenv("OCRGPU_COMM_WINDOWS") != NULL) /* one node: no collective, ocrgpu_exchange then runs over the windows */
+                return rcclShareWindowHandles(ocrgpuBinding.location, ocrgpuBinding.nLocations);
             toReturn = rcclShareUniqueId(ocrgpuBinding.location, id);
             if(toReturn) return toReturn;
             OCRGPU_ENTER();
@@ -121,6 +170,7 @@ static u8 rcclCommSwitchRunlevel(ocrCommPlatform_t *self, ocrPolicyDomain_t *PD,
         if((properties & RL_TEAR_DOWN) && RL_IS_LAST_PHASE_DOWN(PD, RL_COMPUTE_OK, phase) && ocrgpuBinding.engine) {
             OCRGPU_ENTER();
             toReturn = ocrgpuToOcrError(ocrgpu_comm_fini(ocrgpuBinding.engine));
+            if(toReturn == 0) toReturn = ocrgpuToOcrError(ocrgpu_peer_fini(ocrgpuBinding.engine));
             OCRGPU_LEAVE();
         }
         break;

@@ -1588,51 +1588,61 @@ __global__ void k_exchange_apply_strided(Dev d, u32 n_src, u64 stride, u32 max_c
 }
 // OCRGPU_STEP_WRITE_HEADERS: {records for this destination, my activity} in the last record slot of every region
 // (end != 0: the run's k_end rides along on lane 0 -- it folds Ctrl.state[K & 1] into the between-runs words and changes nothing the headers read)
-__global__ void k_exchange_headers(Dev d, u32 K, u32 end = 0) {
-    const u32 loc = threadIdx.x;
-    if (end && loc == 0) end_of_run(d, K);
-    if (loc >= d.n_loc) return;
+__device__ __forceinline__ void header_words(const Dev &d, u32 K, u32 loc, u64 *h) {
     const State *S = &d.ctrl->state[K & 1];
     u64 sent = 0;
-    for (u32 l = 0; l < d.n_loc; ++l) { u32 c = d.send_cnt[l * 32]; sent += c > d.send_cap ? d.send_cap : c; }
-    u32 mine = d.send_cnt[loc * 32]; if (mine > d.send_cap) mine = d.send_cap;
-    u64 *h = (u64 *)&d.send[(size_t)loc * d.send_cap + (d.send_cap - 1)];
+    for (u32 l = 0; l < d.n_loc; ++l) { u32 c = d.send_cnt[l * 32]; sent += c > d.send_cap - 1 ? d.send_cap - 1 : c; }
+    u32 mine = d.send_cnt[loc * 32]; if (mine > d.send_cap - 1) mine = d.send_cap - 1;
     // (a step that was launched ahead without a poll may have run out of launches before it was done: that counts as "queued",
     // so that every partition comes back for a settle round)
     // activity = EDTs fired by this step + records sent + "EDTs are ready here" (a partition that caught up late, outside the
     // step its headers describe, still keeps the loop going through what it left ready)
     h[0] = mine; h[1] = (u64)(S->r_end - S->r_begin) + sent + (S->r_total > S->r_end ? 1u : 0u); h[2] = sent; h[3] = (S->q_total > S->q_end ? S->q_total - S->q_end : 0) + (S->done ? 0u : 1u);
 }
+__global__ void k_exchange_headers(Dev d, u32 K, u32 end = 0) {
+    const u32 loc = threadIdx.x;
+    if (end && loc == 0) end_of_run(d, K);
+    if (loc >= d.n_loc) return;
+    header_words(d, K, loc, (u64 *)&d.send[(size_t)loc * d.send_cap + (d.send_cap - 1)]);
+}
 // the receive side of the equal-split exchange, counts taken from the headers on the device (no host read in between):
 // region s of `recs` (stride records, header in the last slot) carries hdr[0] records from partition s
-__global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec *recs, u32 db_floor, const u32 *skip) {
-    if (skip && *skip) return; // (peer windows: a source did not arrive, the regions are not this round's)
-    const u32 per = gridDim.x / n_src; // workgroups per source: the grid is n_src * per, whatever the regions' capacity
-    const u32 s = blockIdx.x / per, part = blockIdx.x % per;
-    if (s >= n_src) return;
-    u64 cnt = recs[(u64)s * stride + (stride - 1)].guid; // header word 0
-    if (cnt > stride - 1) cnt = stride - 1;
-    for (u64 k = part * (u64)blockDim.x + threadIdx.x; k < cnt; k += per * (u64)blockDim.x) apply_record(d, recs[(u64)s * stride + k], db_floor);
-}
-__global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
-// reset + header sums + report in ONE launch (they were three): the send counters start the next step at zero, the sums of the
-// received headers and the state / error words go straight into the pinned page the host reads after its one synchronisation
-__global__ void k_exchange_finish(Dev d, u32 K, u32 n_src, u64 stride, const SendRec *recs, u32 *pin) {
+// reset + header sums + report: the send counters start the next step at zero, the sums of the received headers and the state /
+// error words go straight into the pinned page the host reads after its one synchronisation.  Any workgroup size.
+__device__ void exchange_finish(const Dev &d, u32 K, u32 n_src, u64 stride, const SendRec *recs, u32 *pin) {
     __shared__ unsigned long long sum[4];
     const u32 t = threadIdx.x;
     if (t < 4) sum[t] = 0;
     __syncthreads();
-    if (t < d.n_loc) d.send_cnt[t * 32] = 0;
-    if (t < n_src) {
-        const u64 *h = (const u64 *)&recs[(u64)t * stride + (stride - 1)];
+    for (u32 l = t; l < d.n_loc; l += blockDim.x) d.send_cnt[l * 32] = 0;
+    for (u32 x = t; x < n_src; x += blockDim.x) {
+        const u64 *h = (const u64 *)&recs[(u64)x * stride + (stride - 1)];
         for (u32 k = 0; k < 4; ++k) if (h[k]) atomicAdd(&sum[k], (unsigned long long)h[k]);
     }
     __syncthreads();
     if (t < 4) reinterpret_cast<u64 *>(pin + 33040)[t] = sum[t];
     const Ctrl *c = d.ctrl;
     if (t < 32) pin[t] = reinterpret_cast<const u32 *>(&c->state[K & 1])[t];
-    if (t < 8) pin[33020 + t] = c->err[t];
+    if (t < 8) pin[33020 + t] = __hip_atomic_load(&c->err[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (other workgroups' atomics of this launch)
 }
+// the apply of a round; its LAST workgroup to finish also does the round's exchange_finish (one launch less per level)
+__global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec *recs, u32 db_floor, const u32 *skip, u32 K, u32 *pin, u32 *done_cnt) {
+    if (skip && *skip) return; // (peer windows: a source did not arrive, the regions are not this round's; the host call fails on the late count)
+    const u32 per = gridDim.x / n_src; // workgroups per source: the grid is n_src * per, whatever the regions' capacity
+    const u32 s = blockIdx.x / per, part = blockIdx.x % per;
+    if (s < n_src) {
+        u64 cnt = recs[(u64)s * stride + (stride - 1)].guid; // header word 0
+        if (cnt > stride - 1) cnt = stride - 1;
+        for (u64 k = part * (u64)blockDim.x + threadIdx.x; k < cnt; k += per * (u64)blockDim.x) apply_record(d, recs[(u64)s * stride + k], db_floor);
+    }
+    __shared__ u32 last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) { last = atomicAdd(done_cnt, 1u) == gridDim.x - 1 ? 1u : 0u; if (last) *done_cnt = 0; }
+    __syncthreads();
+    if (last) exchange_finish(d, K, n_src, stride, recs, pin);
+}
+__global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
 
 // ---- peer windows: the exchange of one node without a collective.  Every partition owns a WINDOW in its GPU's memory (fine-grained,
 //      so that what peers write over xGMI is seen by the kernels that read it): one arrival word per source partition (64-byte
@@ -1650,13 +1660,14 @@ __host__ __device__ __forceinline__ size_t peer_regions_off(u32 n_loc) { return 
 __device__ __forceinline__ SendRec *peer_region(char *base, u32 n_loc, u64 cap, u32 parity, u32 src) {
     return (SendRec *)(base + peer_regions_off(n_loc)) + ((size_t)parity * n_loc + src) * cap;
 }
-__global__ void k_peer_push(Dev d, PeerDev pd, u64 round) {
+__global__ void k_peer_push(Dev d, PeerDev pd, u64 round, u32 K, u32 end) {
     const u32 p = blockIdx.x / PEER_PUSH_BLOCKS, part = blockIdx.x % PEER_PUSH_BLOCKS;
+    if (end && blockIdx.x == 0 && threadIdx.x == 0) end_of_run(d, K); // (k_end rides along: it changes nothing that is read here)
     u32 cnt = d.send_cnt[p * 32]; if (cnt > d.send_cap - 1) cnt = d.send_cap - 1;
     const uint4 *src = (const uint4 *)(d.send + (size_t)p * d.send_cap);
     uint4 *dst = (uint4 *)peer_region(pd.base[p], d.n_loc, d.send_cap, (u32)(round & 1), pd.me);
     for (u64 i = part * (u64)blockDim.x + threadIdx.x; i < 2 * (u64)cnt; i += PEER_PUSH_BLOCKS * (u64)blockDim.x) dst[i] = src[i];
-    if (part == 0 && threadIdx.x < 2) dst[2 * (u64)(d.send_cap - 1) + threadIdx.x] = src[2 * (u64)(d.send_cap - 1) + threadIdx.x]; // the header (k_exchange_headers)
+    if (part == 0 && threadIdx.x == 0) header_words(d, K, p, (u64 *)(dst + 2 * (u64)(d.send_cap - 1))); // the header goes straight into the window
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(&pd.cnt[p], 1u) == PEER_PUSH_BLOCKS - 1) { // the last of p's workgroups: everybody's stores are out
@@ -1683,7 +1694,7 @@ __global__ void k_peer_wait(Dev d, PeerDev pd, u64 round, u64 limit, u32 *pin) {
     __syncthreads();
     if (s == 0) { pd.cnt[1024] = late; pin[PIN_PEER_LATE] = late; }
 }
-__global__ void k_exchange_counts(Dev d, u32 *out) { if (threadIdx.x < d.n_loc) { u32 c = d.send_cnt[threadIdx.x * 32]; out[threadIdx.x] = c > d.send_cap ? d.send_cap : c; } }
+__global__ void k_exchange_counts(Dev d, u32 *out) { if (threadIdx.x < d.n_loc) { u32 c = d.send_cnt[threadIdx.x * 32]; out[threadIdx.x] = c > d.send_cap - 1 ? d.send_cap - 1 : c; } }
 
 // SCHED_GET_WORK for EDTs whose bodies run on the host (hcSchedulerHeuristicGetEdt, hc-scheduler-heuristic.c:148-199,
 // feeding taskExecute hc-task.c:1864): compact the OCRBODY_HOST EDTs of fired[begin,end) with what their body needs --
@@ -2003,7 +2014,7 @@ struct ocrgpu_engine {
     void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records; u64 *xsum_dev;
     // peer windows (ocrgpu_peer_*): my window, the device table of everybody's, what was opened from other processes, the round
     // counter every partition advances together, the wait limit in wall-clock ticks; hdr_fresh: the step just queued wrote the headers
-    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> *peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; bool peer_on, hdr_fresh, ahead_timed;
+    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> *peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; bool peer_on, hdr_fresh, ahead_timed, end_pending;
     u64 *wp; u64 wp_cap, wp_head, wp_tail; // workpile: ring of guids in HBM, indices kept by the (single) caller side
     // reclaimed capacity (ocrgpu_reclaim, ocrgpu_db_destroy): device tables, host mirrors of the free-stack heights and of the
     // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
@@ -2107,7 +2118,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     ocrgpu_engine *e = new ocrgpu_engine();
     e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
     e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0; e->xsum_dev = nullptr;
-    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_opened = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false;
+    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_opened = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false;
     e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
     memset(&e->rc, 0, sizeof e->rc); e->n_free_edt = e->n_free_evt = e->n_free_db = e->n_held = 0; e->mut_epoch = 0; e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
@@ -2707,7 +2718,7 @@ extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *
     if (pending_records_out) *pending_records_out = S->q_total > S->q_end ? S->q_total - S->q_end : 0;
     if (send_counts_out) {
         if (!e->d.send_cnt) FAIL(OCRGPU_EINVAL, "exchange not configured");
-        for (u32 l = 0; l < e->d.n_loc; ++l) { u32 c = e->pinned_done[32 + 32 * l]; send_counts_out[l] = c > e->d.send_cap ? e->d.send_cap : c; }
+        for (u32 l = 0; l < e->d.n_loc; ++l) { u32 c = e->pinned_done[32 + 32 * l]; send_counts_out[l] = c > e->d.send_cap - 1 ? e->d.send_cap - 1 : c; }
     }
     e->hdr_fresh = (flags & OCRGPU_STEP_WRITE_HEADERS) != 0;
     return check_fault(e); // the outputs above are filled either way
@@ -2990,6 +3001,10 @@ extern "C" int ocrgpu_comm_alltoall(ocrgpu_engine_t *e, const void *send_dev, vo
 // One exchange round, in three stages so that the same protocol runs over RCCL (one engine per process) and over plain
 // device-to-device copies (several partitions in one process: the tests).  xchg_post: headers into the send regions.
 // xchg_land: apply what arrived, clear the send counters, bring back the header sums (the round's ONE synchronisation).
+static int xchg_words(ocrgpu_engine *e) { // [0,1024) push workgroups done per destination, [1024] sources late, [1025] apply workgroups done
+    if (e->peer_cnt) return 0;
+    return dalloc(e, (void **)&e->peer_cnt, 4 * 1032);
+}
 static int xchg_post(ocrgpu_engine *e, bool hdr_fresh) {
     int r = e->peer_on ? 0 : exchange_buffers(e); if (r) return r;
     if (e->d.n_loc > 1024) FAIL(OCRGPU_EINVAL, "more than 1024 locations");
@@ -3000,9 +3015,9 @@ static int xchg_post(ocrgpu_engine *e, bool hdr_fresh) {
 static int xchg_land(ocrgpu_engine *e, const SendRec *recs, const u32 *skip, u64 *out4) {
     Dev &d = e->d;
     u32 per = (d.send_cap + 254u) / 256u; if (per > 32u) per = 32u; // workgroups per source region
-    k_exchange_apply_hdr<<<d.n_loc * per, 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, recs, e->n_db, skip);
+    int r = xchg_words(e); if (r) return r;
     // the header sums, the state the last step ended in and the error counters ride on the same synchronisation (step_ahead does not poll)
-    k_exchange_finish<<<1, 1024, 0, e->stream>>>(d, e->launch_index, d.n_loc, d.send_cap, recs, e->pinned_dev);
+    k_exchange_apply_hdr<<<d.n_loc * per, 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, recs, e->n_db, skip, e->launch_index, e->pinned_dev, e->peer_cnt + 1025);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->stream));
     memcpy(out4, e->pinned_done + 33040, 32);
@@ -3058,7 +3073,7 @@ extern "C" int ocrgpu_peer_connect(ocrgpu_engine_t *e, const void *handles) {
         opened->push_back(q); base[p] = (char *)q;
     }
     if (!e->peer_base_dev) { int r = dalloc(e, (void **)&e->peer_base_dev, 8 * 1024); if (r) { undo(); return r; } }
-    if (!e->peer_cnt) { int r = dalloc(e, (void **)&e->peer_cnt, 4 * 1032); if (r) { undo(); return r; } }
+    { int r = xchg_words(e); if (r) { undo(); return r; } }
     HIPCHK(hipMemcpyAsync(e->peer_base_dev, base.data(), 8 * (size_t)d.n_loc, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     const char *ms = getenv("OCRGPU_PEER_TIMEOUT_MS");
@@ -3077,13 +3092,14 @@ extern "C" int ocrgpu_peer_fini(ocrgpu_engine_t *e) {
 }
 // one round over the windows for the partitions of this process (1 with one process per GPU): every push is queued before any
 // wait, so partitions that share a hardware queue cannot wait on a push that sits behind them
-static int peer_exchange(ocrgpu_engine **g, u32 n, const bool *fresh, u64 *h) {
+static int peer_exchange(ocrgpu_engine **g, u32 n, u64 *h) {
     for (u32 i = 0; i < n; ++i) {
         ocrgpu_engine *e = g[i]; Dev &d = e->d;
         HIPCHK(hipSetDevice(e->device));
-        int r = xchg_post(e, fresh[i]); if (r) return r;
+        if (d.n_loc > 1024) FAIL(OCRGPU_EINVAL, "more than 1024 locations");
         const PeerDev pd{e->peer_base_dev, e->peer_win, e->cfg.location, e->peer_cnt};
-        k_peer_push<<<d.n_loc * PEER_PUSH_BLOCKS, 256, 0, e->stream>>>(d, pd, e->peer_round);
+        k_peer_push<<<d.n_loc * PEER_PUSH_BLOCKS, 256, 0, e->stream>>>(d, pd, e->peer_round, e->launch_index, e->end_pending ? 1u : 0u); // (the headers are made here)
+        e->end_pending = false;
         HIPCHK(hipGetLastError());
     }
     for (u32 i = 0; i < n; ++i) {
@@ -3104,7 +3120,7 @@ extern "C" int ocrgpu_exchange(ocrgpu_engine_t *e, u64 *records_in_out, u64 *act
     ENTER(e);
     if (!e->comm && !e->peer_on) FAIL(OCRGPU_EINVAL, "no transport (ocrgpu_comm_init or ocrgpu_peer_connect)");
     u64 h[4]; int r;
-    if (e->peer_on) { if ((r = peer_exchange(&e, 1, &fresh, h))) return r; }
+    if (e->peer_on) { if ((r = peer_exchange(&e, 1, h))) return r; }
     else {
         if ((r = xchg_post(e, fresh))) return r;
         if ((r = ocrgpu_comm_alltoall(e, e->d.send, e->recv_buf, sizeof(SendRec) * (u64)e->d.send_cap))) return r;
@@ -3126,7 +3142,7 @@ extern "C" int ocrgpu_exchange_local(ocrgpu_engine_t **engines, u32 n, u64 *acti
     for (u32 i = 0; i < n; ++i) { fresh[i] = engines[i]->hdr_fresh; engines[i]->hdr_fresh = false; n_peer += engines[i]->peer_on ? 1u : 0u; }
     if (n_peer) { // the group is connected by windows: the same protocol as between processes
         if (n_peer != n) FAIL(OCRGPU_EINVAL, "some engines of the group are connected by peer windows, some are not");
-        u64 h[4]; int r = peer_exchange(engines, n, fresh, h); if (r) return r;
+        u64 h[4]; int r = peer_exchange(engines, n, h); if (r) return r;
         if (activity_out) *activity_out = h[1];
         if (sent_out) *sent_out = h[2];
         if (queued_out) *queued_out = h[3];
@@ -3187,9 +3203,9 @@ static int step_ahead(ocrgpu_engine *e, u32 fire, u32 flags, u32 n_launch, bool 
     if (timed) { HIPCHK(hipEventRecord(e->ev1, e->stream)); e->ahead_timed = true; }
     e->launches_total += n_launch; e->launch_index = K - 1;
     if (d.n_loc <= 1) { k_end<<<1, 1, 0, e->stream>>>(d, K - 1); k_owed_bodies<<<grid, BLK, 0, e->stream>>>(d); k_owed_clear<<<1, 1, 0, e->stream>>>(d); } // (with partitions bodies run before the fan-out: nothing is owed)
-    k_exchange_headers<<<1, 1024, 0, e->stream>>>(d, e->launch_index, d.n_loc <= 1 ? 0u : 1u);
+    if (e->peer_on && d.n_loc > 1) e->end_pending = true; // peer windows: the push kernel of the exchange that follows makes the headers and carries k_end
+    else { k_exchange_headers<<<1, 1024, 0, e->stream>>>(d, e->launch_index, d.n_loc <= 1 ? 0u : 1u); e->hdr_fresh = true; }
     HIPCHK(hipGetLastError());
-    e->hdr_fresh = true;
     return 0;
 }
 static int group_round(ocrgpu_engine **g, u32 n, bool rccl, u32 fire, u32 step_flags, u64 *h, double *tm, int *fault, bool timed = false, u32 n_fire = 4u) {
