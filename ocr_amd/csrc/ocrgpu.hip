@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(BLK) void k_owed_bodies(Dev d) { deferred_bodies<tr
 __global__ void k_owed_clear(Dev d) { d.ctrl->b_begin = d.ctrl->b_end = 0; }
 
 // Start a run at launch index K0: seed state[(K0-1)&1] from the between-runs view (single thread).
-__global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) {
+__device__ __forceinline__ void begin_run(const Dev &d, u32 K0, u32 allow_fire, u32 force_level) {
     Ctrl *c = d.ctrl;
     if (force_level & 2u) { // OCRGPU_STEP_DROP_EMPTY_LEVEL: forget a trailing forced level in which nothing fired
         const u32 lv = c->level;
@@ -1165,6 +1165,27 @@ __global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) {
     c->cnt_r[(K0 - 1) % 3].v = 0; c->cnt_q[(K0 - 1) % 3].v = 0;
     c->cnt_r[K0 % 3].v = 0; c->cnt_q[K0 % 3].v = 0;
 }
+__global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) { begin_run(d, K0, allow_fire, force_level); }
+// Rounds queued AHEAD of the host (ocrgpu_resolve_exchange over peer windows): what a round is -- the next level, a settle round,
+// the rest of a step that ran out of launches, or nothing because the run is over -- is decided here, on the device, from the
+// words the last round's apply left (RA_*: taken from the exchanged header sums, so every partition decides alike).
+#define RA_STOP 1026u   // the run is over: rounds still queued do nothing (they still push and wait, so nobody hangs)
+#define RA_HOLD 1027u   // something is still in flight or queued somewhere: the next round settles, it does not fire
+#define RA_LEVELS 1028u // levels closed with activity
+#define RA_KIND 1029u   // this round: 1 = fires a level, 0 = settles, 2 = idle
+#define RA_ACT 1030u    // (u64, 8-byte aligned) activity of the level so far
+__global__ void k_ra_init(u32 *w) { w[RA_STOP] = 0; w[RA_HOLD] = 0; w[RA_LEVELS] = 0; w[RA_KIND] = 0; w[RA_ACT] = 0; w[RA_ACT + 1] = 0; }
+__device__ __forceinline__ void begin_auto(const Dev &d, u32 K0, u32 *w) {
+    u32 fire = 0, force = 0;
+    if (w[RA_STOP]) w[RA_KIND] = 2;
+    else if (w[RA_HOLD]) {
+        const State *P = &d.ctrl->state[(K0 - 1) & 1]; // how the last run ended: one that ran out of launches goes on with what it had left
+        if (!P->done) { fire = P->allow_fire; force = fire ? OCRGPU_STEP_FORCE_LEVEL : 0u; }
+        w[RA_KIND] = 0;
+    } else { fire = 1; force = OCRGPU_STEP_FORCE_LEVEL; w[RA_KIND] = 1; w[RA_ACT] = 0; w[RA_ACT + 1] = 0; }
+    begin_run(d, K0, fire, force);
+}
+__global__ void k_begin_auto(Dev d, u32 K0, u32 *w) { begin_auto(d, K0, w); }
 // End of a run whose last launch was K: fold the run state back into the between-runs view; if the record
 // log is fully consumed, rewind it (keeps q_cap small).
 __device__ __forceinline__ void end_of_run(const Dev &d, u32 K) {
@@ -1609,8 +1630,7 @@ __global__ void k_exchange_headers(Dev d, u32 K, u32 end = 0) {
 // region s of `recs` (stride records, header in the last slot) carries hdr[0] records from partition s
 // reset + header sums + report: the send counters start the next step at zero, the sums of the received headers and the state /
 // error words go straight into the pinned page the host reads after its one synchronisation.  Any workgroup size.
-__device__ void exchange_finish(const Dev &d, u32 K, u32 n_src, u64 stride, const SendRec *recs, u32 *pin) {
-    __shared__ unsigned long long sum[4];
+__device__ void exchange_finish(const Dev &d, u32 K, u32 n_src, u64 stride, const SendRec *recs, u32 *pin, unsigned long long *sum /* LDS, [4] */) {
     const u32 t = threadIdx.x;
     if (t < 4) sum[t] = 0;
     __syncthreads();
@@ -1625,22 +1645,63 @@ __device__ void exchange_finish(const Dev &d, u32 K, u32 n_src, u64 stride, cons
     if (t < 32) pin[t] = reinterpret_cast<const u32 *>(&c->state[K & 1])[t];
     if (t < 8) pin[33020 + t] = __hip_atomic_load(&c->err[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (other workgroups' atomics of this launch)
 }
-// the apply of a round; its LAST workgroup to finish also does the round's exchange_finish (one launch less per level)
-__global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec *recs, u32 db_floor, const u32 *skip, u32 K, u32 *pin, u32 *done_cnt) {
-    if (skip && *skip) return; // (peer windows: a source did not arrive, the regions are not this round's; the host call fails on the late count)
+#define PEER_PUSH_BLOCKS 16u
+#define PIN_PEER_LATE 33050u
+struct PeerDev { char *const *base; char *mine; u32 me; u32 *cnt; }; // cnt[p] = push workgroups done for p; cnt[1024] = waits that gave up (sticky)
+__device__ __forceinline__ u64 *peer_arrival(char *base, u32 src) { return (u64 *)(base + 64 * (size_t)src); }
+// The apply of a round.  Peer windows (`win` = my window): the workgroups of source s first WAIT for s's arrival word of this
+// round (system-scope acquire loads, bounded by `limit` ticks of the 100 MHz wall clock; a wait that gives up is counted in
+// words[1024], which is sticky: nothing is waited for or applied after it, and the host call fails).  The LAST workgroup to
+// finish does the round's exchange_finish, and for rounds queued ahead of the host (`ra_on`) takes the host loop's decisions
+// and starts the next round's run (begin_auto) -- wait, apply, finish and begin in ONE launch.
+#define PIN_RA 33052u // pin[PIN_RA..+4) = {RA_STOP, RA_LEVELS, RA_HOLD, rounds applied} after each round queued ahead
+__global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec *recs, u32 db_floor, u32 K, u32 *pin, u32 *words,
+                                     char *win, u64 round, u64 limit, u32 ra_on, u32 no_cascade, u32 next_K0) {
     const u32 per = gridDim.x / n_src; // workgroups per source: the grid is n_src * per, whatever the regions' capacity
     const u32 s = blockIdx.x / per, part = blockIdx.x % per;
-    if (s < n_src) {
+    __shared__ u32 ok, last;
+    if (threadIdx.x == 0) {
+        ok = 1;
+        if (win) {
+            if (__hip_atomic_load(&words[1024], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = 0;
+            else {
+                const u64 *f = peer_arrival(win, s);
+                const u64 t0 = wall_clock64();
+                while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < round + 1) {
+                    if (wall_clock64() - t0 > limit) { ok = 0; atomicAdd(&words[1024], 1u); break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (ok) {
         u64 cnt = recs[(u64)s * stride + (stride - 1)].guid; // header word 0
         if (cnt > stride - 1) cnt = stride - 1;
         for (u64 k = part * (u64)blockDim.x + threadIdx.x; k < cnt; k += per * (u64)blockDim.x) apply_record(d, recs[(u64)s * stride + k], db_floor);
     }
-    __shared__ u32 last;
     __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) { last = atomicAdd(done_cnt, 1u) == gridDim.x - 1 ? 1u : 0u; if (last) *done_cnt = 0; }
+    if (threadIdx.x == 0) { last = atomicAdd(&words[1025], 1u) == gridDim.x - 1 ? 1u : 0u; if (last) words[1025] = 0; }
     __syncthreads();
-    if (last) exchange_finish(d, K, n_src, stride, recs, pin);
+    if (!last) return;
+    __shared__ unsigned long long sum[4];
+    const u32 late = win ? __hip_atomic_load(&words[1024], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (!late) exchange_finish(d, K, n_src, stride, recs, pin, sum);
+    if (threadIdx.x != 0) return;
+    if (win) pin[PIN_PEER_LATE] = late;
+    if (!ra_on) return;
+    u32 *ra = words; // the host loop's decisions (resolve_exchange_group), taken here
+    const u32 kind = ra[RA_KIND];
+    if (late) ra[RA_STOP] = 1;
+    else if (kind != 2u) {
+        u64 act = *reinterpret_cast<u64 *>(&ra[RA_ACT]) + sum[1];
+        const bool pending = (kind == 1u && no_cascade) ? sum[3] != 0 : (sum[2] != 0 || sum[3] != 0);
+        if (pending) { ra[RA_HOLD] = 1; *reinterpret_cast<u64 *>(&ra[RA_ACT]) = act; }
+        else { ra[RA_HOLD] = 0; if (act == 0) ra[RA_STOP] = 1; else ra[RA_LEVELS] += 1; *reinterpret_cast<u64 *>(&ra[RA_ACT]) = 0; }
+    }
+    pin[PIN_RA] = ra[RA_STOP]; pin[PIN_RA + 1] = ra[RA_LEVELS]; pin[PIN_RA + 2] = ra[RA_HOLD];
+    if (next_K0) begin_auto(d, next_K0, ra);
 }
 __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
 
@@ -1652,10 +1713,6 @@ __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[
 //      p's arrival word [me] = round + 1; a one-workgroup kernel of the RECEIVER waits for all its arrival words (bounded), and the
 //      apply kernel follows it on the stream.  Two parities are enough: a sender starts round r + 2 only after it has seen every
 //      partition's arrival for r + 1, which each of them stored after its own apply of round r (stream order). ----
-#define PEER_PUSH_BLOCKS 16u
-#define PIN_PEER_LATE 33050u
-struct PeerDev { char *const *base; char *mine; u32 me; u32 *cnt; }; // cnt[p] = push workgroups done for p; cnt[1024] = sources late last round
-__device__ __forceinline__ u64 *peer_arrival(char *base, u32 src) { return (u64 *)(base + 64 * (size_t)src); }
 __host__ __device__ __forceinline__ size_t peer_regions_off(u32 n_loc) { return ((64 * (size_t)n_loc + 255) / 256) * 256; }
 __device__ __forceinline__ SendRec *peer_region(char *base, u32 n_loc, u64 cap, u32 parity, u32 src) {
     return (SendRec *)(base + peer_regions_off(n_loc)) + ((size_t)parity * n_loc + src) * cap;
@@ -1675,24 +1732,6 @@ __global__ void k_peer_push(Dev d, PeerDev pd, u64 round, u32 K, u32 end) {
         __threadfence_system();
         __hip_atomic_store(peer_arrival(pd.base[p], pd.me), round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-}
-// one workgroup, one lane per source; `limit` in ticks of the 100 MHz wall clock.  A source that does not arrive in time is
-// counted, the round's records are NOT applied (k_exchange_apply_hdr's `skip`), and the host call fails with that count.
-__global__ void k_peer_wait(Dev d, PeerDev pd, u64 round, u64 limit, u32 *pin) {
-    __shared__ u32 late;
-    const u32 s = threadIdx.x;
-    if (s == 0) late = 0;
-    __syncthreads();
-    if (s < d.n_loc) {
-        const u64 *f = peer_arrival(pd.mine, s);
-        const u64 t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < round + 1) {
-            if (wall_clock64() - t0 > limit) { atomicAdd(&late, 1u); break; }
-            __builtin_amdgcn_s_sleep(4);
-        }
-    }
-    __syncthreads();
-    if (s == 0) { pd.cnt[1024] = late; pin[PIN_PEER_LATE] = late; }
 }
 __global__ void k_exchange_counts(Dev d, u32 *out) { if (threadIdx.x < d.n_loc) { u32 c = d.send_cnt[threadIdx.x * 32]; out[threadIdx.x] = c > d.send_cap - 1 ? d.send_cap - 1 : c; } }
 
@@ -2014,7 +2053,7 @@ struct ocrgpu_engine {
     void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records; u64 *xsum_dev;
     // peer windows (ocrgpu_peer_*): my window, the device table of everybody's, what was opened from other processes, the round
     // counter every partition advances together, the wait limit in wall-clock ticks; hdr_fresh: the step just queued wrote the headers
-    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> *peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; bool peer_on, hdr_fresh, ahead_timed, end_pending;
+    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> *peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; bool peer_on, hdr_fresh, ahead_timed, end_pending; hipEvent_t ra_ev[2];
     u64 *wp; u64 wp_cap, wp_head, wp_tail; // workpile: ring of guids in HBM, indices kept by the (single) caller side
     // reclaimed capacity (ocrgpu_reclaim, ocrgpu_db_destroy): device tables, host mirrors of the free-stack heights and of the
     // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
@@ -2118,7 +2157,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     ocrgpu_engine *e = new ocrgpu_engine();
     e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
     e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0; e->xsum_dev = nullptr;
-    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_opened = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false;
+    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_opened = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false; e->ra_ev[0] = e->ra_ev[1] = nullptr;
     e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
     memset(&e->rc, 0, sizeof e->rc); e->n_free_edt = e->n_free_evt = e->n_free_db = e->n_held = 0; e->mut_epoch = 0; e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
@@ -2251,6 +2290,7 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     if (e->snap.valid) snap_free(e->snap);
     if (e->pinned_done) (void)hipHostFree(e->pinned_done);
     for (int i = 0; i < 2; ++i) if (e->apply_ev[i]) (void)hipEventDestroy(e->apply_ev[i]);
+    for (int i = 0; i < 2; ++i) if (e->ra_ev[i]) (void)hipEventDestroy(e->ra_ev[i]);
     if (e->have_events) { (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1); }
     delete e;
     return 0;
@@ -3001,9 +3041,9 @@ extern "C" int ocrgpu_comm_alltoall(ocrgpu_engine_t *e, const void *send_dev, vo
 // One exchange round, in three stages so that the same protocol runs over RCCL (one engine per process) and over plain
 // device-to-device copies (several partitions in one process: the tests).  xchg_post: headers into the send regions.
 // xchg_land: apply what arrived, clear the send counters, bring back the header sums (the round's ONE synchronisation).
-static int xchg_words(ocrgpu_engine *e) { // [0,1024) push workgroups done per destination, [1024] sources late, [1025] apply workgroups done
+static int xchg_words(ocrgpu_engine *e) { // [0,1024) push workgroups done per destination, [1024] sources late, [1025] apply workgroups done, [1026..1031] RA_*
     if (e->peer_cnt) return 0;
-    return dalloc(e, (void **)&e->peer_cnt, 4 * 1032);
+    return dalloc(e, (void **)&e->peer_cnt, 4 * 1040);
 }
 static int xchg_post(ocrgpu_engine *e, bool hdr_fresh) {
     int r = e->peer_on ? 0 : exchange_buffers(e); if (r) return r;
@@ -3012,13 +3052,15 @@ static int xchg_post(ocrgpu_engine *e, bool hdr_fresh) {
     HIPCHK(hipGetLastError());
     return 0;
 }
-static int xchg_land(ocrgpu_engine *e, const SendRec *recs, const u32 *skip, u64 *out4) {
+static int xchg_land(ocrgpu_engine *e, const SendRec *recs, bool windows, u64 *out4, bool ahead = false, u32 no_cascade = 0, u32 next_K0 = 0) {
     Dev &d = e->d;
     u32 per = (d.send_cap + 254u) / 256u; if (per > 32u) per = 32u; // workgroups per source region
     int r = xchg_words(e); if (r) return r;
     // the header sums, the state the last step ended in and the error counters ride on the same synchronisation (step_ahead does not poll)
-    k_exchange_apply_hdr<<<d.n_loc * per, 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, recs, e->n_db, skip, e->launch_index, e->pinned_dev, e->peer_cnt + 1025);
+    k_exchange_apply_hdr<<<d.n_loc * per, 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, recs, e->n_db, e->launch_index, e->pinned_dev, e->peer_cnt,
+                                                             windows ? e->peer_win : nullptr, e->peer_round, e->peer_limit, ahead ? 1u : 0u, no_cascade, next_K0);
     HIPCHK(hipGetLastError());
+    if (ahead) return 0; // rounds queued ahead: the caller synchronises once per batch
     HIPCHK(hipStreamSynchronize(e->stream));
     memcpy(out4, e->pinned_done + 33040, 32);
     return 0;
@@ -3092,7 +3134,7 @@ extern "C" int ocrgpu_peer_fini(ocrgpu_engine_t *e) {
 }
 // one round over the windows for the partitions of this process (1 with one process per GPU): every push is queued before any
 // wait, so partitions that share a hardware queue cannot wait on a push that sits behind them
-static int peer_exchange(ocrgpu_engine **g, u32 n, u64 *h) {
+static int peer_exchange(ocrgpu_engine **g, u32 n, u64 *h, bool ahead = false, u32 no_cascade = 0, bool next_K0 = false) {
     for (u32 i = 0; i < n; ++i) {
         ocrgpu_engine *e = g[i]; Dev &d = e->d;
         HIPCHK(hipSetDevice(e->device));
@@ -3105,12 +3147,10 @@ static int peer_exchange(ocrgpu_engine **g, u32 n, u64 *h) {
     for (u32 i = 0; i < n; ++i) {
         ocrgpu_engine *e = g[i]; Dev &d = e->d;
         HIPCHK(hipSetDevice(e->device));
-        const PeerDev pd{e->peer_base_dev, e->peer_win, e->cfg.location, e->peer_cnt};
-        k_peer_wait<<<1, 1024, 0, e->stream>>>(d, pd, e->peer_round, e->peer_limit, e->pinned_dev);
         const SendRec *recs = (const SendRec *)(e->peer_win + peer_regions_off(d.n_loc)) + (size_t)(e->peer_round & 1) * d.n_loc * d.send_cap;
+        int r = xchg_land(e, recs, true, h, ahead, no_cascade, next_K0 ? e->launch_index + 1 : 0u); if (r) return r;
         e->peer_round++;
-        int r = xchg_land(e, recs, e->peer_cnt + 1024, h); if (r) return r;
-        if (e->pinned_done[PIN_PEER_LATE]) FAIL(OCRGPU_EHIP, "peer windows: %u of %u partitions did not arrive at location %u within the limit (OCRGPU_PEER_TIMEOUT_MS); "
+        if (!ahead && e->pinned_done[PIN_PEER_LATE]) FAIL(OCRGPU_EHIP, "peer windows: %u of %u partitions did not arrive at location %u within the limit (OCRGPU_PEER_TIMEOUT_MS); "
                                                "the round was not applied and the run cannot continue", e->pinned_done[PIN_PEER_LATE], d.n_loc, e->cfg.location);
     }
     return 0;
@@ -3124,7 +3164,7 @@ extern "C" int ocrgpu_exchange(ocrgpu_engine_t *e, u64 *records_in_out, u64 *act
     else {
         if ((r = xchg_post(e, fresh))) return r;
         if ((r = ocrgpu_comm_alltoall(e, e->d.send, e->recv_buf, sizeof(SendRec) * (u64)e->d.send_cap))) return r;
-        if ((r = xchg_land(e, e->recv_buf, nullptr, h))) return r;
+        if ((r = xchg_land(e, e->recv_buf, false, h))) return r;
     }
     if (records_in_out) *records_in_out = h[0];
     if (activity_out) *activity_out = h[1];
@@ -3160,7 +3200,7 @@ extern "C" int ocrgpu_exchange_local(ocrgpu_engine_t **engines, u32 n, u64 *acti
                                   hipMemcpyDeviceToDevice, engines[dst]->stream));
     for (u32 i = 0; i < n; ++i) HIPCHK(hipStreamSynchronize(engines[i]->stream)); // (the engines may sit on different streams)
     u64 h[4] = {0, 0, 0, 0};
-    for (u32 i = 0; i < n; ++i) { int r = xchg_land(engines[i], engines[i]->recv_buf, nullptr, h); if (r) return r; }
+    for (u32 i = 0; i < n; ++i) { int r = xchg_land(engines[i], engines[i]->recv_buf, false, h); if (r) return r; }
     if (activity_out) *activity_out = h[1];
     if (sent_out) *sent_out = h[2];
     if (queued_out) *queued_out = h[3];
@@ -3232,12 +3272,71 @@ static int group_round(ocrgpu_engine **g, u32 n, bool rccl, u32 fire, u32 step_f
     if (tm) { tm[0] += t1 - t0; tm[1] += now_s() - t1; }
     return 0;
 }
+// The level loop with rounds queued AHEAD of the host (peer windows only: nothing in a round needs the host).  Batches of
+// `ahead` rounds; two batches are kept in flight, so the device never waits for a launch, and the host looks at the pinned
+// report (k_exchange_apply_hdr: stop / levels) once per batch.  Rounds still queued when the run stops are idle ones.
+static int run_ahead_round(ocrgpu_engine **g, u32 n, u32 n_launch, u32 no_cascade, bool first) {
+    for (u32 i = 0; i < n; ++i) {
+        ocrgpu_engine *e = g[i]; Dev &d = e->d;
+        ENTER(e);
+        u32 K = e->launch_index + 1; // (no wrap reset inside a run: the previous round's apply has already begun this K)
+        if (first) k_begin_auto<<<1, 1, 0, e->stream>>>(d, K, e->peer_cnt); // (afterwards the last workgroup of a round's apply begins the next round)
+        const u32 grid = e->step_grid > MAX_GRID ? MAX_GRID : (e->step_grid ? e->step_grid : 256u);
+        for (u32 k = 0; k < n_launch; ++k, ++K) launch_step(e, grid, K);
+        e->launches_total += n_launch; e->launch_index = K - 1;
+        e->end_pending = true; // (k_end and the headers: in the push kernel)
+        HIPCHK(hipGetLastError());
+    }
+    u64 h[4];
+    return peer_exchange(g, n, h, true, no_cascade, true);
+}
+static int resolve_run_ahead(ocrgpu_engine **g, u32 n, u32 flags, u64 *levels_out, int *fault) {
+    const char *ev_ = getenv("OCRGPU_RX_AHEAD"), *nl = getenv("OCRGPU_RX_LAUNCHES");
+    const u32 ahead = ev_ && atoi(ev_) > 0 ? (u32)atoi(ev_) : 8u, no_cascade = (flags & OCRGPU_RX_NO_CASCADE) ? 1u : 0u;
+    const u32 n_launch = nl ? (u32)atoi(nl) : (no_cascade ? 3u : 4u);
+    int r;
+    for (u32 i = 0; i < n; ++i) {
+        ocrgpu_engine *e = g[i];
+        HIPCHK(hipSetDevice(e->device));
+        if ((r = seal(e))) return r;
+        if (e->launch_index > 0xF0000000u) e->launch_index = 8; // keep K-1 and K%3 arithmetic away from the wrap (checked between runs only)
+        if (e->d.n_loc < 2) FAIL(OCRGPU_EINVAL, "rounds are queued ahead for partitioned engines only");
+        for (int k = 0; k < 2; ++k) if (!e->ra_ev[k]) HIPCHK(hipEventCreateWithFlags(&e->ra_ev[k], hipEventDisableTiming));
+        e->pinned_done[PIN_RA] = e->pinned_done[PIN_RA + 1] = e->pinned_done[PIN_RA + 2] = e->pinned_done[PIN_RA + 3] = 0;
+        k_ra_init<<<1, 1, 0, e->stream>>>(e->peer_cnt);
+    }
+    bool stop = false;
+    for (u64 batch = 0; !stop; ++batch) {
+        for (u32 k = 0; k < ahead; ++k) if ((r = run_ahead_round(g, n, n_launch, no_cascade, batch == 0 && k == 0))) return r;
+        for (u32 i = 0; i < n; ++i) { HIPCHK(hipSetDevice(g[i]->device)); HIPCHK(hipEventRecord(g[i]->ra_ev[batch & 1], g[i]->stream)); }
+        if (batch == 0) continue; // keep two batches in flight
+        for (u32 i = 0; i < n; ++i) {
+            HIPCHK(hipEventSynchronize(g[i]->ra_ev[(batch - 1) & 1]));
+            // (every partition takes the same decisions from the same sums; any one's word will do, and it only ever goes 0 -> 1)
+            if (g[i]->pinned_done[PIN_RA] || g[i]->pinned_done[PIN_PEER_LATE]) stop = true;
+        }
+    }
+    for (u32 i = 0; i < n; ++i) { HIPCHK(hipSetDevice(g[i]->device)); HIPCHK(hipStreamSynchronize(g[i]->stream)); }
+    for (u32 i = 0; i < n; ++i) {
+        ocrgpu_engine *e = g[i];
+        if (e->pinned_done[PIN_PEER_LATE]) FAIL(OCRGPU_EHIP, "peer windows: %u of %u partitions did not arrive at location %u within the limit (OCRGPU_PEER_TIMEOUT_MS); "
+                                               "the run cannot continue", e->pinned_done[PIN_PEER_LATE], e->d.n_loc, e->cfg.location);
+        if (!e->pinned_done[PIN_RA]) FAIL(OCRGPU_EHIP, "rounds queued ahead ended without the stop word at location %u", e->cfg.location);
+        if (check_fault(e) == OCRGPU_EFAULT) *fault = OCRGPU_EFAULT;
+    }
+    *levels_out = g[0]->pinned_done[PIN_RA + 1];
+    return 0;
+}
 static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags, u64 *levels_out) {
     u64 h[4] = {0, 0, 0, 0}, levels = 0;
     double tm[2] = {0, 0}; const bool timing = getenv("OCRGPU_DIST_TIMING") != nullptr;
     int r, fault = 0; const bool timed = (flags & OCRGPU_RX_TIME_STEPS) != 0;
     do { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, nullptr, &fault, timed))) return r; } while (h[2] || h[3]); // what the main program sent settles first
-    for (;;) {
+    bool all_peer = g[0]->d.n_loc > 1;
+    for (u32 i = 0; i < n; ++i) all_peer = all_peer && g[i]->peer_on;
+    const bool queue_ahead = all_peer && !timed && !timing && !getenv("OCRGPU_RX_POLLED") && !getenv("OCRGPU_RX_NO_AHEAD");
+    if (queue_ahead) { if ((r = resolve_run_ahead(g, n, flags, &levels, &fault))) return r; }
+    else for (;;) {
         // launches queued for a level: the records that arrived, the level itself, the one that notices the end; one more where
         // arrivals may fire events that send on (a step that needs more says so and is finished with polls)
         if ((r = group_round(g, n, rccl, 1u, OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault, timed, (flags & OCRGPU_RX_NO_CASCADE) ? 3u : 4u))) return r;

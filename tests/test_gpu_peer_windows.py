@@ -38,6 +38,38 @@ def test_windows_in_one_process_are_partition_invariant(name, world):
     assert res.diff(O.run_restatement(s)) == []
 
 
+@pytest.mark.parametrize("mode", ["budget1", "budget2_ahead1", "ahead3", "host_driven", "host_driven_budget1"])
+@pytest.mark.parametrize("name", ["layered_1k", "event_chain", "counted_events", "channel_events", "cholesky_T8", "wide_fanin",
+                                  "sticky_early_and_late"])
+def test_rounds_queued_ahead_decide_on_the_device(name, mode, monkeypatch):
+    """Over the windows the level loop queues rounds ahead of the host; whether a round fires the next level, settles, finishes a
+    step that ran out of launches, or idles because the run is over is decided on the device from the exchanged sums.  A budget of
+    one launch per round makes every step run out; batches of 1 and 3 rounds move the points where the host looks; "host_driven"
+    is the loop with one synchronisation per level (OCRGPU_RX_NO_AHEAD), which must agree."""
+    if "budget1" in mode:
+        monkeypatch.setenv("OCRGPU_RX_LAUNCHES", "1")
+    if "budget2" in mode:
+        monkeypatch.setenv("OCRGPU_RX_LAUNCHES", "2")
+    if "ahead1" in mode:
+        monkeypatch.setenv("OCRGPU_RX_AHEAD", "1")
+    if "ahead3" in mode:
+        monkeypatch.setenv("OCRGPU_RX_AHEAD", "3")
+    if "host_driven" in mode:
+        monkeypatch.setenv("OCRGPU_RX_NO_AHEAD", "1")
+    s = ALL[name]
+    parts = D.build_lockstep([D.Partition(s, r, 3) for r in range(3)])
+    D.connect_peer_windows(parts)
+    levels = D.resolve_lockstep_c(parts)
+    res = D.gather_result_lockstep(s, parts)
+    errs = [list(p.eng.stats().err) for p in parts]
+    for p in parts:
+        p.eng.close()
+    want = O.run_restatement(s)
+    assert all(sum(e) == 0 for e in errs), errs
+    assert res.diff(want) == []
+    assert levels == int(want.level.max()) + 1
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_windows_one_exchange_per_level_rearmed(world):
     from ocr_amd.workloads import LayeredPartition

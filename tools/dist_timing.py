@@ -10,7 +10,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("OCRGPU_DIST_TIMING", "1")
+if not (sys.argv[1:] and sys.argv[1].startswith("windows")):   # (the per-stage timing keeps the loop host-driven: not for the windows runs)
+    os.environ.setdefault("OCRGPU_DIST_TIMING", "1")
 
 from ocr_amd import distributed as D          # noqa: E402
 from ocr_amd import engine as E               # noqa: E402
