@@ -1311,7 +1311,13 @@ __global__ void k_edt_create(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n, c
 }
 
 __device__ __forceinline__ void q_push(const Dev &d, Rec r) {
-    u32 qi = atomicAdd(&d.ctrl->q_tail, 1u);
+    // one atomic per wavefront for the lanes that are here together (a round's apply queues thousands of records: one atomic each on
+    // this single word was most of that kernel's time)
+    const u64 m = __ballot(1);
+    const u32 lane = __lane_id(), leader = (u32)__ffsll((unsigned long long)m) - 1u;
+    u32 base = 0;
+    if (lane == leader) base = atomicAdd(&d.ctrl->q_tail, (u32)__popcll(m));
+    const u32 qi = __shfl(base, leader) + (u32)__popcll(m & ((1ull << lane) - 1ull));
     if (qi < d.q_cap) d.q[qi] = r; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
 }
 __device__ __forceinline__ void bad_op(const Dev &d) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); }
