@@ -1174,7 +1174,9 @@ __global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) { begin_
 #define RA_LEVELS 1028u // levels closed with activity
 #define RA_KIND 1029u   // this round: 1 = fires a level, 0 = settles, 2 = idle
 #define RA_ACT 1030u    // (u64, 8-byte aligned) activity of the level so far
-__global__ void k_ra_init(u32 *w) { w[RA_STOP] = 0; w[RA_HOLD] = 0; w[RA_LEVELS] = 0; w[RA_KIND] = 0; w[RA_ACT] = 0; w[RA_ACT + 1] = 0; }
+#define RA_ROUND 1032u  // rounds applied since k_ra_init
+#define RA_STOP_AT 1033u // 1 + the round in which RA_STOP was set (what the host goes by: see resolve_run_ahead)
+__global__ void k_ra_init(u32 *w) { w[RA_STOP] = 0; w[RA_HOLD] = 0; w[RA_LEVELS] = 0; w[RA_KIND] = 0; w[RA_ACT] = 0; w[RA_ACT + 1] = 0; w[RA_ROUND] = 0; w[RA_STOP_AT] = 0; }
 __device__ __forceinline__ void begin_auto(const Dev &d, u32 K0, u32 *w) {
     u32 fire = 0, force = 0;
     if (w[RA_STOP]) w[RA_KIND] = 2;
@@ -1660,7 +1662,7 @@ __device__ __forceinline__ u64 *peer_arrival(char *base, u32 src) { return (u64 
 // words[1024], which is sticky: nothing is waited for or applied after it, and the host call fails).  The LAST workgroup to
 // finish does the round's exchange_finish, and for rounds queued ahead of the host (`ra_on`) takes the host loop's decisions
 // and starts the next round's run (begin_auto) -- wait, apply, finish and begin in ONE launch.
-#define PIN_RA 33052u // pin[PIN_RA..+4) = {RA_STOP, RA_LEVELS, RA_HOLD, rounds applied} after each round queued ahead
+#define PIN_RA 33052u // pin[PIN_RA..+4) = {RA_STOP_AT, RA_LEVELS, RA_HOLD, rounds applied} after each round queued ahead
 __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec *recs, u32 db_floor, u32 K, u32 *pin, u32 *words,
                                      char *win, u64 round, u64 limit, u32 ra_on, u32 no_cascade, u32 next_K0) {
     const u32 per = gridDim.x / n_src; // workgroups per source: the grid is n_src * per, whatever the regions' capacity
@@ -1706,7 +1708,10 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
         if (pending) { ra[RA_HOLD] = 1; *reinterpret_cast<u64 *>(&ra[RA_ACT]) = act; }
         else { ra[RA_HOLD] = 0; if (act == 0) ra[RA_STOP] = 1; else ra[RA_LEVELS] += 1; *reinterpret_cast<u64 *>(&ra[RA_ACT]) = 0; }
     }
-    pin[PIN_RA] = ra[RA_STOP]; pin[PIN_RA + 1] = ra[RA_LEVELS]; pin[PIN_RA + 2] = ra[RA_HOLD];
+    const u32 round_no = ra[RA_ROUND]; ra[RA_ROUND] = round_no + 1;
+    if (ra[RA_STOP] && !ra[RA_STOP_AT]) ra[RA_STOP_AT] = round_no + 1;
+    pin[PIN_RA + 1] = ra[RA_LEVELS]; pin[PIN_RA + 2] = ra[RA_HOLD]; pin[PIN_RA + 3] = round_no + 1;
+    pin[PIN_RA] = ra[RA_STOP_AT]; // 0 = still running; else 1 + the round that ended the run
     if (next_K0) begin_auto(d, next_K0, ra);
 }
 __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[threadIdx.x * 32] = 0; }
@@ -1716,8 +1721,8 @@ __global__ void k_exchange_reset(Dev d) { if (threadIdx.x < d.n_loc) d.send_cnt[
 //      stride), then two sets (round parity) of n_loc receive regions of send_cap records.  Each partition maps every other
 //      partition's window (hipIpcOpenMemHandle across processes, the plain pointer within one) and, per round, a kernel of the
 //      SENDER stores the records it has for p -- only those, plus the header -- into region [parity][me] of p's window and then
-//      p's arrival word [me] = round + 1; a one-workgroup kernel of the RECEIVER waits for all its arrival words (bounded), and the
-//      apply kernel follows it on the stream.  Two parities are enough: a sender starts round r + 2 only after it has seen every
+//      p's arrival word [me] = round + 1; the RECEIVER's apply kernel waits for its arrival words first (bounded; the workgroups of
+//      source s wait for s's word).  Two parities are enough: a sender starts round r + 2 only after it has seen every
 //      partition's arrival for r + 1, which each of them stored after its own apply of round r (stream order). ----
 __host__ __device__ __forceinline__ size_t peer_regions_off(u32 n_loc) { return ((64 * (size_t)n_loc + 255) / 256) * 256; }
 __device__ __forceinline__ SendRec *peer_region(char *base, u32 n_loc, u64 cap, u32 parity, u32 src) {
@@ -3318,8 +3323,12 @@ static int resolve_run_ahead(ocrgpu_engine **g, u32 n, u32 flags, u64 *levels_ou
         if (batch == 0) continue; // keep two batches in flight
         for (u32 i = 0; i < n; ++i) {
             HIPCHK(hipEventSynchronize(g[i]->ra_ev[(batch - 1) & 1]));
-            // (every partition takes the same decisions from the same sums; any one's word will do, and it only ever goes 0 -> 1)
-            if (g[i]->pinned_done[PIN_RA] || g[i]->pinned_done[PIN_PEER_LATE]) stop = true;
+            // Every partition takes the same decisions from the same sums, and every PROCESS must queue the same number of rounds
+            // (a round of one pairs with the same round of the others): so the stop counts only once the batch it fell in is
+            // known to be complete -- a host that happens to look late and sees a stop from the batch still running ignores it
+            // until the next look.  The run ends after the batch that follows the stopping one, everywhere.
+            const u32 at = g[i]->pinned_done[PIN_RA];
+            if ((at && (u64)(at - 1) < batch * (u64)ahead) || g[i]->pinned_done[PIN_PEER_LATE]) stop = true;
         }
     }
     for (u32 i = 0; i < n; ++i) { HIPCHK(hipSetDevice(g[i]->device)); HIPCHK(hipStreamSynchronize(g[i]->stream)); }

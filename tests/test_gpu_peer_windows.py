@@ -163,8 +163,12 @@ def _worker(rank, world, port, n, width, q):
     q.put(out)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_processes_sharing_one_gpu_windows_over_ipc(world):
+@pytest.mark.parametrize("world,ahead", [(2, None), (3, None), (2, "1"), (3, "2")])
+def test_processes_sharing_one_gpu_windows_over_ipc(world, ahead, monkeypatch):
+    """(ahead: rounds per batch -- small batches make the processes look at the stop word at many different moments; each
+    must still queue exactly as many rounds as the others, or rounds would pair up wrongly across processes)"""
+    if ahead:
+        monkeypatch.setenv("OCRGPU_RX_AHEAD", ahead)
     width = 1200 if world == 3 else 1000
     n = 36_000 if world == 3 else 40_000
     ref = O.run_restatement(layered_dag(n, width))
