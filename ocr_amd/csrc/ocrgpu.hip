@@ -112,7 +112,7 @@ struct DbLock { u32 state, ew, itw, ro; };
 // Phase state of launch K.  EVERY workgroup of launch K derives it from state[(K-1)&1] and the append counters
 // of launch K-1 (all stable once K-1 has ended), so no workgroup waits for another: no ticket, no grid barrier.
 struct alignas(128) State {
-    u32 mode, level, r_begin, r_end, q_begin, q_end, done, allow_fire;
+    u32 mode, level, r_begin, r_end, q_begin, q_end, done /* word 6: exchange_finish */, allow_fire;
     u32 r_total, q_total;   // log positions where this launch's appends start
     u32 n_levels, force_level;
     u32 b_begin, b_end;     // ready-log range of the level fired by this launch whose bodies were left for the next launch
@@ -1159,7 +1159,8 @@ __device__ __forceinline__ void begin_run(const Dev &d, u32 K0, u32 allow_fire, 
     }
     State P; memset(&P, 0, sizeof P);
     P.mode = MODE_EVENTS; P.level = c->level; P.r_begin = P.r_end = c->r_end; P.q_begin = P.q_end = c->q_begin;
-    P.done = 0; P.allow_fire = allow_fire; P.r_total = c->r_tail; P.q_total = c->q_tail > d.q_cap ? d.q_cap : c->q_tail;
+    const u32 r_tail = __hip_atomic_load(&c->r_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), q_tail = __hip_atomic_load(&c->q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    P.done = 0; P.allow_fire = allow_fire; P.r_total = r_tail; P.q_total = q_tail > d.q_cap ? d.q_cap : q_tail; // (atomic loads: the apply kernel's last workgroup begins the next run)
     P.n_levels = c->n_levels; P.force_level = force_level; P.b_begin = c->b_begin; P.b_end = c->b_end;
     c->state[(K0 - 1) & 1] = P;
     c->cnt_r[(K0 - 1) % 3].v = 0; c->cnt_q[(K0 - 1) % 3].v = 0;
@@ -1190,6 +1191,20 @@ __device__ __forceinline__ void begin_auto(const Dev &d, u32 K0, u32 *w) {
 __global__ void k_begin_auto(Dev d, u32 K0, u32 *w) { begin_auto(d, K0, w); }
 // End of a run whose last launch was K: fold the run state back into the between-runs view; if the record
 // log is fully consumed, rewind it (keeps q_cap small).
+// What launch K + 1 would find, without launching it: the log totals with launch K's appends, and whether it would only notice that
+// the run is over (k_step's phase decision: nothing queued, no fire budget left, no bodies owed).  The level loops across
+// partitions go by this instead of paying a launch per level for the notice.
+struct RunView { u32 r_total, q_total; bool over; };
+__device__ __forceinline__ RunView run_view(const Dev &d, u32 K) {
+    const Ctrl *c = d.ctrl;
+    const State *N = &c->state[K & 1];
+    RunView v{N->r_total, N->q_total, true};
+    if (N->done) return v;
+    v.r_total += c->cnt_r[K % 3].v; v.q_total += c->cnt_q[K % 3].v;
+    if (v.q_total > d.q_cap) v.q_total = d.q_cap;
+    v.over = !(v.q_total > N->q_end) && !N->allow_fire && !(N->b_end > N->b_begin);
+    return v;
+}
 __device__ __forceinline__ void end_of_run(const Dev &d, u32 K) {
     Ctrl *c = d.ctrl;
     const State P = c->state[K & 1];
@@ -1199,7 +1214,7 @@ __device__ __forceinline__ void end_of_run(const Dev &d, u32 K) {
     c->r_tail = P.r_total + (P.done ? 0u : c->cnt_r[K % 3].v);
     u32 qt = P.q_total + (P.done ? 0u : c->cnt_q[K % 3].v);
     c->q_begin = P.q_end; c->q_tail = qt;
-    if (P.done && P.q_end >= qt) { c->q_begin = 0; c->q_tail = 0; }
+    if ((P.done || (!P.allow_fire && !(P.b_end > P.b_begin))) && P.q_end >= qt) { c->q_begin = 0; c->q_tail = 0; } // (over, noticed or not: run_view)
 }
 __global__ void k_end(Dev d, u32 K) { end_of_run(d, K); }
 
@@ -1563,6 +1578,15 @@ __global__ void k_script_merge_latch(Dev d, u64 n, const u32 *begin, const u32 *
 // Apply satisfies received from other partitions: resolve the guid in OUR table, clone the DB into a proxy
 // entry, and queue an ordinary record (the next EVENTS phase does the rest).
 // `db_floor` = explicit datablocks created so far (host mirror): proxies grow down from max_db and must not reach them
+// the lanes of a wavefront that are here together reserve `1` each on one counter with ONE atomic (a round's apply brings thousands
+// of records: one atomic each on a single word is what such a kernel's time goes into)
+__device__ __forceinline__ u32 wave_reserve_one(u32 *counter) {
+    const u64 m = __ballot(1);
+    const u32 lane = __lane_id(), leader = (u32)__ffsll((unsigned long long)m) - 1u;
+    u32 base = 0;
+    if (lane == leader) base = atomicAdd(counter, (u32)__popcll(m));
+    return __shfl(base, leader) + (u32)__popcll(m & ((1ull << lane) - 1ull));
+}
 __device__ void apply_record(const Dev &d, const SendRec &r, u32 db_floor) {
     if (r.flags & XF_DESTROY) {
         u64 v = (OCRGPU_GUID_LOCATION(r.guid) == d.location && is_event_kind(OCRGPU_GUID_KIND(r.guid))) ? gtab_get(d, r.guid) : 0;
@@ -1595,7 +1619,7 @@ __device__ void apply_record(const Dev &d, const SendRec &r, u32 db_floor) {
     }
     u32 pay = 0;
     if (r.flags & XF_HAS_DB) { // only a record that carries a datablock takes a proxy entry
-        const u32 pi = atomicAdd(&d.ctrl->proxy_used, 1u);
+        const u32 pi = wave_reserve_one(&d.ctrl->proxy_used);
         if ((u64)pi + 1 + db_floor > d.max_db) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
         const u32 proxy = d.max_db - 1u - pi;
         d.db[proxy] = make_ulonglong2(r.value, r.tag); pay = proxy + 1;
@@ -1617,6 +1641,7 @@ __global__ void k_exchange_apply_strided(Dev d, u32 n_src, u64 stride, u32 max_c
 }
 // OCRGPU_STEP_WRITE_HEADERS: {records for this destination, my activity} in the last record slot of every region
 // (end != 0: the run's k_end rides along on lane 0 -- it folds Ctrl.state[K & 1] into the between-runs words and changes nothing the headers read)
+#define HDR_BEHIND (1ull << 40) // in header word 3 (sums: how many partitions): the step was to fire a level and has not got to it
 __device__ __forceinline__ void header_words(const Dev &d, u32 K, u32 loc, u64 *h) {
     const State *S = &d.ctrl->state[K & 1];
     u64 sent = 0;
@@ -1626,7 +1651,9 @@ __device__ __forceinline__ void header_words(const Dev &d, u32 K, u32 loc, u64 *
     // so that every partition comes back for a settle round)
     // activity = EDTs fired by this step + records sent + "EDTs are ready here" (a partition that caught up late, outside the
     // step its headers describe, still keeps the loop going through what it left ready)
-    h[0] = mine; h[1] = (u64)(S->r_end - S->r_begin) + sent + (S->r_total > S->r_end ? 1u : 0u); h[2] = sent; h[3] = (S->q_total > S->q_end ? S->q_total - S->q_end : 0) + (S->done ? 0u : 1u);
+    const RunView v = run_view(d, K); // (as the launch that only notices the end would have left it)
+    h[0] = mine; h[1] = (u64)(S->r_end - S->r_begin) + sent + (v.r_total > S->r_end ? 1u : 0u); h[2] = sent; h[3] = (v.q_total > S->q_end ? v.q_total - S->q_end : 0) + (v.over ? 0u : 1u)
+           + ((S->allow_fire != 0u && S->allow_fire != 0xFFFFFFFFu && !S->done) ? HDR_BEHIND : 0ull); // a level was asked for and has not fired here yet
 }
 __global__ void k_exchange_headers(Dev d, u32 K, u32 end = 0) {
     const u32 loc = threadIdx.x;
@@ -1650,7 +1677,7 @@ __device__ void exchange_finish(const Dev &d, u32 K, u32 n_src, u64 stride, cons
     __syncthreads();
     if (t < 4) reinterpret_cast<u64 *>(pin + 33040)[t] = sum[t];
     const Ctrl *c = d.ctrl;
-    if (t < 32) pin[t] = reinterpret_cast<const u32 *>(&c->state[K & 1])[t];
+    if (t < 32) pin[t] = t == 6 ? (run_view(d, K).over ? 1u : 0u) : reinterpret_cast<const u32 *>(&c->state[K & 1])[t]; // word 6 = State.done
     if (t < 8) pin[33020 + t] = __hip_atomic_load(&c->err[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (other workgroups' atomics of this launch)
 }
 #define PEER_PUSH_BLOCKS 16u
@@ -1701,6 +1728,12 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
     if (!ra_on) return;
     u32 *ra = words; // the host loop's decisions (resolve_exchange_group), taken here
     const u32 kind = ra[RA_KIND];
+    // OCRGPU_RX_NO_CASCADE fires the next level without a settle round, so the records of a level arrive at a partition that has
+    // not fired that level yet if its launches went into the previous level's arrivals: what they make ready would fire a level
+    // early.  (With settle rounds every queue is empty when a level fires.)  The host-driven loop finishes such a step with polls
+    // before the exchange; rounds queued ahead cannot, and stop with an error instead of mislabelling.
+    const u32 behind = (u32)(sum[3] >> 40);
+    if (!late && kind == 1u && no_cascade && behind != 0u && behind != n_src) { ra[RA_STOP] = 1; pin[PIN_RA + 2] = 0xBAD0BAD0u; }
     if (late) ra[RA_STOP] = 1;
     else if (kind != 2u) {
         u64 act = *reinterpret_cast<u64 *>(&ra[RA_ACT]) + sum[1];
@@ -1710,7 +1743,7 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
     }
     const u32 round_no = ra[RA_ROUND]; ra[RA_ROUND] = round_no + 1;
     if (ra[RA_STOP] && !ra[RA_STOP_AT]) ra[RA_STOP_AT] = round_no + 1;
-    pin[PIN_RA + 1] = ra[RA_LEVELS]; pin[PIN_RA + 2] = ra[RA_HOLD]; pin[PIN_RA + 3] = round_no + 1;
+    pin[PIN_RA + 1] = ra[RA_LEVELS]; if (pin[PIN_RA + 2] != 0xBAD0BAD0u) pin[PIN_RA + 2] = ra[RA_HOLD]; pin[PIN_RA + 3] = round_no + 1;
     pin[PIN_RA] = ra[RA_STOP_AT]; // 0 = still running; else 1 + the round that ended the run
     if (next_K0) begin_auto(d, next_K0, ra);
 }
@@ -3074,6 +3107,7 @@ static int xchg_land(ocrgpu_engine *e, const SendRec *recs, bool windows, u64 *o
     if (ahead) return 0; // rounds queued ahead: the caller synchronises once per batch
     HIPCHK(hipStreamSynchronize(e->stream));
     memcpy(out4, e->pinned_done + 33040, 32);
+    out4[3] &= HDR_BEHIND - 1; // (a partition that is behind is not over either: it has counted itself in the low bits too)
     return 0;
 }
 
@@ -3304,7 +3338,7 @@ static int run_ahead_round(ocrgpu_engine **g, u32 n, u32 n_launch, u32 no_cascad
 static int resolve_run_ahead(ocrgpu_engine **g, u32 n, u32 flags, u64 *levels_out, int *fault) {
     const char *ev_ = getenv("OCRGPU_RX_AHEAD"), *nl = getenv("OCRGPU_RX_LAUNCHES");
     const u32 ahead = ev_ && atoi(ev_) > 0 ? (u32)atoi(ev_) : 8u, no_cascade = (flags & OCRGPU_RX_NO_CASCADE) ? 1u : 0u;
-    const u32 n_launch = nl ? (u32)atoi(nl) : (no_cascade ? 3u : 4u);
+    const u32 n_launch = nl ? (u32)atoi(nl) : (no_cascade ? 2u : 3u); // (the arrivals, the level; that the run is over is seen without a launch: run_view)
     int r;
     for (u32 i = 0; i < n; ++i) {
         ocrgpu_engine *e = g[i];
@@ -3337,6 +3371,9 @@ static int resolve_run_ahead(ocrgpu_engine **g, u32 n, u32 flags, u64 *levels_ou
         if (e->pinned_done[PIN_PEER_LATE]) FAIL(OCRGPU_EHIP, "peer windows: %u of %u partitions did not arrive at location %u within the limit (OCRGPU_PEER_TIMEOUT_MS); "
                                                "the run cannot continue", e->pinned_done[PIN_PEER_LATE], e->d.n_loc, e->cfg.location);
         if (!e->pinned_done[PIN_RA]) FAIL(OCRGPU_EHIP, "rounds queued ahead ended without the stop word at location %u", e->cfg.location);
+        if (e->pinned_done[PIN_RA + 2] == 0xBAD0BAD0u) FAIL(OCRGPU_EINVAL, "OCRGPU_RX_NO_CASCADE: a partition had not fired its level when the others' records of that level arrived "
+                                                                            "(its launches went into what the arrivals of the level before set off); the run was stopped. Resolve without "
+                                                                            "OCRGPU_RX_NO_CASCADE, or with OCRGPU_RX_NO_AHEAD=1 / a larger OCRGPU_RX_LAUNCHES");
         if (check_fault(e) == OCRGPU_EFAULT) *fault = OCRGPU_EFAULT;
     }
     *levels_out = g[0]->pinned_done[PIN_RA + 1];
@@ -3352,9 +3389,10 @@ static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags
     const bool queue_ahead = all_peer && !timed && !timing && !getenv("OCRGPU_RX_POLLED") && !getenv("OCRGPU_RX_NO_AHEAD");
     if (queue_ahead) { if ((r = resolve_run_ahead(g, n, flags, &levels, &fault))) return r; }
     else for (;;) {
-        // launches queued for a level: the records that arrived, the level itself, the one that notices the end; one more where
-        // arrivals may fire events that send on (a step that needs more says so and is finished with polls)
-        if ((r = group_round(g, n, rccl, 1u, OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault, timed, (flags & OCRGPU_RX_NO_CASCADE) ? 3u : 4u))) return r;
+        // launches queued for a level: the records that arrived, the level itself (that the run is then over is seen without a
+        // launch: run_view); one more where arrivals may fire events that send on (a step that needs more says so and is
+        // finished with polls)
+        if ((r = group_round(g, n, rccl, 1u, OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault, timed, (flags & OCRGPU_RX_NO_CASCADE) ? 2u : 3u))) return r;
         u64 act = h[1];
         if (!(flags & OCRGPU_RX_NO_CASCADE) || h[3])
             while (h[2] || h[3]) { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault, timed))) return r; act += h[1]; }

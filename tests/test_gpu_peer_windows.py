@@ -99,6 +99,41 @@ def test_windows_one_exchange_per_level_rearmed(world):
         p.eng.close()
 
 
+@pytest.mark.parametrize("host_driven", [False, True])
+def test_no_cascade_with_too_few_launches(host_driven, monkeypatch):
+    """OCRGPU_RX_NO_CASCADE fires the next level without a settle round.  With ONE launch per level a partition whose launch went
+    into the last level's arrivals (here: the leaves' DECRs of the latch on partition 0) has not fired when the others' records of
+    the level arrive.  The host-driven loop finishes its step with polls first and stays exact; rounds queued ahead go on when ALL
+    partitions are behind alike (nobody has sent the level yet) and otherwise notice (the headers say who is behind) and stop
+    with an error instead of firing EDTs a level early: exact or refused, never silently wrong."""
+    from ocr_amd.workloads import LayeredPartition
+    monkeypatch.setenv("OCRGPU_RX_LAUNCHES", "1")
+    if host_driven:
+        monkeypatch.setenv("OCRGPU_RX_NO_AHEAD", "1")
+    n, width, world = 60_000, 1500, 2
+    ref = O.run_restatement(layered_dag(n, width))
+    parts = [LayeredPartition(n, width, r, world, allreduce_sum=None) for r in range(world)]
+    total_leaves = sum(len(p.leaves) for p in parts)
+    for p in parts:
+        p.n_leaves = total_leaves
+        p.build()
+    D.connect_peer_windows(parts)
+    D._lockstep_exchange(parts)
+    parts[0].satisfy_start()
+    try:
+        levels = D.resolve_lockstep_c(parts, no_cascade=True)
+    except E.OcrGpuError as ex:          # queued ahead only, and only with that reason: never a silently wrong record
+        assert not host_driven and "had not fired its level" in str(ex)
+    else:
+        assert levels == int(ref.level.max()) + 1
+        for p in parts:
+            lv, val = p.check()
+            ids = np.r_[p.mine, n] if p.rank == 0 else p.mine
+            assert np.array_equal(lv, ref.level[ids]) and np.array_equal(val, ref.val[ids])
+    for p in parts:
+        p.eng.close()
+
+
 def test_a_partition_that_does_not_arrive_fails_the_round(monkeypatch):
     """two partitions connected, only one of them exchanges: its wait gives up after OCRGPU_PEER_TIMEOUT_MS and the call fails"""
     monkeypatch.setenv("OCRGPU_PEER_TIMEOUT_MS", "50")
