@@ -323,9 +323,14 @@ int ocrgpu_exchange_local(ocrgpu_engine_t **engines, uint32_t n, uint64_t *activ
 /* The worker loop across partitions (hc-dist's role for this path, hc-dist-policy.c:1027-1031,2208): settle what the main
  * program sent, then per level {ocrgpu_step(1 level, forced), exchange, settle} until no partition fired or sent anything.  Levels
  * are closed everywhere before the next one fires: the record equals the single-partition one.  Collective over the
- * communicator.  OCRGPU_RX_NO_CASCADE: no satisfy that arrives from another partition ever sends one on (no event -> remote
- * waiter chains), so one exchange per level settles it (two host synchronisations per level: the step's, the exchange's).
- * OCRGPU_DIST_TIMING=1 in the environment: location 0 prints where a level's wall time went. */
+ * communicator / the windows.  OCRGPU_RX_NO_CASCADE: no satisfy that arrives from another partition ever sends one on (no event
+ * -> remote waiter chains) and what it sets off locally is done in ONE launch, so one exchange per level settles it.
+ * One host synchronisation per level; over peer windows none: rounds are queued ahead of the host in batches (OCRGPU_RX_AHEAD,
+ * default 8; OCRGPU_RX_NO_AHEAD=1 keeps the host-driven loop) and what a round is -- next level, settle, rest of a step that ran
+ * out of launches (OCRGPU_RX_LAUNCHES), idle after the end -- is decided on the device from the exchanged header sums, alike on
+ * every partition.  A NO_CASCADE run in which a partition falls a level behind the others is stopped with OCRGPU_EINVAL rather
+ * than mislabelled (the host-driven loop catches such a step up with polls instead).
+ * OCRGPU_DIST_TIMING=1 in the environment: location 0 prints where a level's wall time went (host-driven loop). */
 #define OCRGPU_RX_NO_CASCADE 1u
 /* OCRGPU_RX_TIME_STEPS (engines made with OCRGPU_F_TIMING): HIP events around every level's k_step launches, summed into
  * ocrgpu_stats_t.step_kernel_ns.  Two event records per level: for a profiling pass, not for the pass whose wall time is reported. */
