@@ -259,6 +259,7 @@ def windows_up(part, torch, dist, rank, world):
     window with hipIpcOpenMemHandle; one node, which is what this bench runs on) and run one empty exchange round over them.
     Used only if EVERY rank got through both stages; otherwise the windows are dropped again and the next transport is tried."""
     from ocr_amd.distributed import connect_peer_windows_dist
+    os.environ.setdefault("OCRGPU_PEER_TIMEOUT_MS", "5000")   # ranks enter a resolve within milliseconds of each other; a wait this long is a failure
     why = ""
     try:
         connect_peer_windows_dist(part, dist)
