@@ -667,22 +667,22 @@ __device__ __forceinline__ void emit_remote(const Dev &d, u64 guid, u32 slot, u3
 __device__ void emit_remote_raw(const Dev &d, u64 guid, u32 slot, u32 xflags, u64 value, u64 tag) {
     u32 loc = OCRGPU_GUID_LOCATION(guid);
     if (d.send == nullptr || loc >= d.n_loc) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
-    // the lanes of this wavefront that are here together with the same destination take ONE atomic on its counter: a level
-    // of the bench's DAG queues ~5000 records per destination, and one atomic each on a single word took 110 us of the launch
+    // The lanes of this wavefront that are here together with the same destination take ONE atomic on its counter (a level of the
+    // bench's DAG queues ~5000 records per destination; one atomic each on a single word took 110 us of the launch), and the
+    // atomics of the different destinations go out TOGETHER: the groups are found first (ballots, no memory), then the lowest
+    // lane of every group reserves for it in one instruction -- one round trip, however many destinations the wavefront has.
     const u32 lane = __lane_id();
-    u64 todo = __ballot(1);
-    u32 pos = 0;
+    u64 todo = __ballot(1), mine = 0;
     while (todo) {
-        const u32 leader = (u32)__ffsll((unsigned long long)todo) - 1u;
-        const u32 lloc = __shfl(loc, leader);
-        const u64 same = __ballot(loc == lloc);
-        if (loc == lloc) {
-            u32 base = 0;
-            if (lane == leader) base = atomicAdd(&d.send_cnt[lloc * 32], (u32)__popcll(same));
-            pos = __shfl(base, leader) + (u32)__popcll(same & ((1ull << lane) - 1ull));
-        }
+        const u32 first = (u32)__ffsll((unsigned long long)todo) - 1u;
+        const u64 same = __ballot(loc == __shfl(loc, first));
+        if (same & (1ull << lane)) mine = same;
         todo &= ~same;
     }
+    const u32 leader = (u32)__ffsll((unsigned long long)mine) - 1u;
+    u32 base = 0;
+    if (lane == leader) base = atomicAdd(&d.send_cnt[loc * 32], (u32)__popcll(mine));
+    const u32 pos = __shfl(base, leader) + (u32)__popcll(mine & ((1ull << lane) - 1ull));
     if (pos + 1 >= d.send_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // (the last slot of a region is its header)
     d.send[(size_t)loc * d.send_cap + pos] = SendRec{guid, slot, xflags, value, tag};
 }
@@ -1642,10 +1642,19 @@ __global__ void k_exchange_apply_strided(Dev d, u32 n_src, u64 stride, u32 max_c
 // OCRGPU_STEP_WRITE_HEADERS: {records for this destination, my activity} in the last record slot of every region
 // (end != 0: the run's k_end rides along on lane 0 -- it folds Ctrl.state[K & 1] into the between-runs words and changes nothing the headers read)
 #define HDR_BEHIND (1ull << 40) // in header word 3 (sums: how many partitions): the step was to fire a level and has not got to it
-__device__ __forceinline__ void header_words(const Dev &d, u32 K, u32 loc, u64 *h) {
+// records queued for all destinations together, by the whole workgroup (one lane alone would make n_loc dependent trips to memory:
+// 8 us of the push kernel at 8 partitions); every lane gets the sum
+__device__ __forceinline__ u64 records_sent_block(const Dev &d, unsigned long long *lds /* one word */) {
+    if (threadIdx.x == 0) *lds = 0;
+    __syncthreads();
+    unsigned long long part = 0;
+    for (u32 l = threadIdx.x; l < d.n_loc; l += blockDim.x) { u32 c = d.send_cnt[l * 32]; part += c > d.send_cap - 1 ? d.send_cap - 1 : c; }
+    if (part) atomicAdd(lds, part);
+    __syncthreads();
+    return *lds;
+}
+__device__ __forceinline__ void header_words(const Dev &d, u32 K, u32 loc, u64 *h, u64 sent) {
     const State *S = &d.ctrl->state[K & 1];
-    u64 sent = 0;
-    for (u32 l = 0; l < d.n_loc; ++l) { u32 c = d.send_cnt[l * 32]; sent += c > d.send_cap - 1 ? d.send_cap - 1 : c; }
     u32 mine = d.send_cnt[loc * 32]; if (mine > d.send_cap - 1) mine = d.send_cap - 1;
     // (a step that was launched ahead without a poll may have run out of launches before it was done: that counts as "queued",
     // so that every partition comes back for a settle round)
@@ -1657,9 +1666,11 @@ __device__ __forceinline__ void header_words(const Dev &d, u32 K, u32 loc, u64 *
 }
 __global__ void k_exchange_headers(Dev d, u32 K, u32 end = 0) {
     const u32 loc = threadIdx.x;
+    __shared__ unsigned long long lds_sent;
     if (end && loc == 0) end_of_run(d, K);
+    const u64 sent = records_sent_block(d, &lds_sent);
     if (loc >= d.n_loc) return;
-    header_words(d, K, loc, (u64 *)&d.send[(size_t)loc * d.send_cap + (d.send_cap - 1)]);
+    header_words(d, K, loc, (u64 *)&d.send[(size_t)loc * d.send_cap + (d.send_cap - 1)], sent);
 }
 // the receive side of the equal-split exchange, counts taken from the headers on the device (no host read in between):
 // region s of `recs` (stride records, header in the last slot) carries hdr[0] records from partition s
@@ -1680,7 +1691,9 @@ __device__ void exchange_finish(const Dev &d, u32 K, u32 n_src, u64 stride, cons
     if (t < 32) pin[t] = t == 6 ? (run_view(d, K).over ? 1u : 0u) : reinterpret_cast<const u32 *>(&c->state[K & 1])[t]; // word 6 = State.done
     if (t < 8) pin[33020 + t] = __hip_atomic_load(&c->err[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (other workgroups' atomics of this launch)
 }
-#define PEER_PUSH_BLOCKS 16u
+// workgroups of the push kernel per destination: 16 for 2 partitions, 8 for 4, 4 from 8 on (measured with 2 / 4 / 8 partitions on one
+// GPU: every workgroup ends in a system-scope fence, and 128 of those cost more than the parallel copy gains)
+__host__ __device__ __forceinline__ u32 peer_push_blocks(u32 n_loc) { const u32 b = 32u / (n_loc ? n_loc : 1u); return b > 16u ? 16u : b < 4u ? 4u : b; }
 #define PIN_PEER_LATE 33050u
 struct PeerDev { char *const *base; char *mine; u32 me; u32 *cnt; }; // cnt[p] = push workgroups done for p; cnt[1024] = waits that gave up (sticky)
 __device__ __forceinline__ u64 *peer_arrival(char *base, u32 src) { return (u64 *)(base + 64 * (size_t)src); }
@@ -1762,16 +1775,24 @@ __device__ __forceinline__ SendRec *peer_region(char *base, u32 n_loc, u64 cap, 
     return (SendRec *)(base + peer_regions_off(n_loc)) + ((size_t)parity * n_loc + src) * cap;
 }
 __global__ void k_peer_push(Dev d, PeerDev pd, u64 round, u32 K, u32 end) {
-    const u32 p = blockIdx.x / PEER_PUSH_BLOCKS, part = blockIdx.x % PEER_PUSH_BLOCKS;
+    const u32 per_dest = peer_push_blocks(d.n_loc);
+    const u32 p = blockIdx.x / per_dest, part = blockIdx.x % per_dest;
     if (end && blockIdx.x == 0 && threadIdx.x == 0) end_of_run(d, K); // (k_end rides along: it changes nothing that is read here)
     u32 cnt = d.send_cnt[p * 32]; if (cnt > d.send_cap - 1) cnt = d.send_cap - 1;
     const uint4 *src = (const uint4 *)(d.send + (size_t)p * d.send_cap);
     uint4 *dst = (uint4 *)peer_region(pd.base[p], d.n_loc, d.send_cap, (u32)(round & 1), pd.me);
-    for (u64 i = part * (u64)blockDim.x + threadIdx.x; i < 2 * (u64)cnt; i += PEER_PUSH_BLOCKS * (u64)blockDim.x) dst[i] = src[i];
-    if (part == 0 && threadIdx.x == 0) header_words(d, K, p, (u64 *)(dst + 2 * (u64)(d.send_cap - 1))); // the header goes straight into the window
+    for (u64 i = part * (u64)blockDim.x + threadIdx.x; i < 2 * (u64)cnt; i += per_dest * (u64)blockDim.x) dst[i] = src[i];
+    if (part == 0) { // the header goes straight into the window (uniform branch: the whole workgroup adds up what was sent)
+        __shared__ unsigned long long lds_sent;
+        const u64 sent = records_sent_block(d, &lds_sent);
+        if (threadIdx.x == 0) header_words(d, K, p, (u64 *)(dst + 2 * (u64)(d.send_cap - 1)), sent);
+    }
+    // Every workgroup releases its stores at SYSTEM scope before it is counted (fence - atomic - atomic - fence: the last workgroup's
+    // fence in front of the arrival word then orders everybody's records before it, for an observer on another GPU too).  Such a
+    // fence writes the L2 back each time, which is why a destination gets few workgroups when there are many destinations.
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&pd.cnt[p], 1u) == PEER_PUSH_BLOCKS - 1) { // the last of p's workgroups: everybody's stores are out
+    if (threadIdx.x == 0 && atomicAdd(&pd.cnt[p], 1u) == per_dest - 1) { // the last of p's workgroups: everybody's stores are out
         pd.cnt[p] = 0;
         __threadfence_system();
         __hip_atomic_store(peer_arrival(pd.base[p], pd.me), round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3185,7 +3206,7 @@ static int peer_exchange(ocrgpu_engine **g, u32 n, u64 *h, bool ahead = false, u
         HIPCHK(hipSetDevice(e->device));
         if (d.n_loc > 1024) FAIL(OCRGPU_EINVAL, "more than 1024 locations");
         const PeerDev pd{e->peer_base_dev, e->peer_win, e->cfg.location, e->peer_cnt};
-        k_peer_push<<<d.n_loc * PEER_PUSH_BLOCKS, 256, 0, e->stream>>>(d, pd, e->peer_round, e->launch_index, e->end_pending ? 1u : 0u); // (the headers are made here)
+        k_peer_push<<<d.n_loc * peer_push_blocks(d.n_loc), 256, 0, e->stream>>>(d, pd, e->peer_round, e->launch_index, e->end_pending ? 1u : 0u); // (the headers are made here)
         e->end_pending = false;
         HIPCHK(hipGetLastError());
     }

@@ -76,10 +76,14 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["windows2"]:
         run(2, False, False, windows=True)
         sys.exit(0)
+    if sys.argv[1:] == ["windows8"]:
+        run(8, False, False, windows=True)
+        sys.exit(0)
     if sys.argv[1:] == ["windows"]:
         run(1, True, False, windows=True)
         run(2, False, False, windows=True)
         run(4, False, False, windows=True)
+        run(8, False, False, windows=True)
         sys.exit(0)
     for world, rccl in ((1, True), (2, False)):
         for polled in (True, False):
