@@ -3182,6 +3182,8 @@ extern "C" int ocrgpu_peer_connect(ocrgpu_engine_t *e, const void *handles) {
     }
     if (!e->peer_base_dev) { int r = dalloc(e, (void **)&e->peer_base_dev, 8 * 1024); if (r) { undo(); return r; } }
     { int r = xchg_words(e); if (r) { undo(); return r; } }
+    HIPCHK(hipMemsetAsync(e->peer_cnt, 0, 4 * 1040, e->stream)); // (a window that gave up waiting earlier starts afresh: the late count is sticky)
+    e->pinned_done[PIN_PEER_LATE] = 0;
     HIPCHK(hipMemcpyAsync(e->peer_base_dev, base.data(), 8 * (size_t)d.n_loc, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     const char *ms = getenv("OCRGPU_PEER_TIMEOUT_MS");

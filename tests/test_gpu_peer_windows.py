@@ -146,6 +146,26 @@ def test_a_partition_that_does_not_arrive_fails_the_round(monkeypatch):
         p.eng.close()
 
 
+def test_windows_can_be_dropped_and_made_again(monkeypatch):
+    """peer_fini frees the window; a new export / connect starts from round 0 with clean arrival words -- also after a wait
+    that gave up (the give-up is sticky only for the window it happened on)"""
+    monkeypatch.setenv("OCRGPU_PEER_TIMEOUT_MS", "50")
+    s = ALL["layered_1k"]
+    parts = D.build_lockstep([D.Partition(s, r, 2) for r in range(2)])
+    D.connect_peer_windows(parts)
+    with pytest.raises(E.OcrGpuError, match="did not arrive"):
+        parts[0].eng.exchange()                    # partition 1 never comes: partition 0's window is dead now
+    for p in parts:
+        p.eng.peer_fini()
+    D.connect_peer_windows(parts)
+    D.resolve_lockstep_c(parts)
+    res = D.gather_result_lockstep(s, parts)
+    for p in parts:
+        assert sum(p.eng.stats().err) == 0
+        p.eng.close()
+    assert res.diff(O.run_restatement(s)) == []
+
+
 def test_handles_of_another_shape_are_refused():
     s = ALL["layered_1k"]
     a, b = D.Partition(s, 0, 2), D.Partition(s, 1, 2)
