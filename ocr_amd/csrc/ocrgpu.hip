@@ -1601,6 +1601,14 @@ __device__ void apply_record(const Dev &d, const SendRec &r, u32 db_floor) {
         counted_activate(d, (u32)(v - 1));
         return;
     }
+    // (the proxy entry of a record that carries a datablock is reserved in front of the table lookup: the two trips overlap)
+    u32 pay = 0;
+    if ((r.flags & XF_HAS_DB) && !(r.flags & XF_LAZYREG)) { // only a record that carries a datablock takes a proxy entry
+        const u32 pi = wave_reserve_one(&d.ctrl->proxy_used);
+        if ((u64)pi + 1 + db_floor > d.max_db) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+        const u32 proxy = d.max_db - 1u - pi;
+        d.db[proxy] = make_ulonglong2(r.value, r.tag); pay = proxy + 1;
+    }
     u32 didx, dslot, dflag;
     if (OCRGPU_GUID_LOCATION(r.guid) != d.location || !resolve_dst(d, r.guid, r.slot, didx, dflag, dslot)) { bad_op(d); return; }
     if (r.flags & XF_LAZYREG) { // same decision as k_add_dep makes for a local COUNTED source
@@ -1616,13 +1624,6 @@ __device__ void apply_record(const Dev &d, const SendRec &r, u32 db_floor) {
             lazy_insert(d, lazy_key(didx, r.slot), r.value);
         } else emit_remote_raw(d, r.value, 0u, XF_ACTIVATE, 0ull, 0ull);
         return;
-    }
-    u32 pay = 0;
-    if (r.flags & XF_HAS_DB) { // only a record that carries a datablock takes a proxy entry
-        const u32 pi = wave_reserve_one(&d.ctrl->proxy_used);
-        if ((u64)pi + 1 + db_floor > d.max_db) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
-        const u32 proxy = d.max_db - 1u - pi;
-        d.db[proxy] = make_ulonglong2(r.value, r.tag); pay = proxy + 1;
     }
     if ((dflag & RF_DST_EDT) && (r.flags & XF_MODE_NULL)) dflag |= RF_MODE_NULL;
     q_push(d, Rec{didx, pay, dslot, dflag});
@@ -2022,8 +2023,8 @@ __global__ void k_reclaim_finish(Dev d, ReclDev rc, u32 compact_log) {
 #define RP_ERR 4u      // pin[PIN_ERR..+8)    = Ctrl.err[]
 #define RP_QUEUE 8u    // pin[33008], [33009] = Ctrl.q_begin, q_tail
 #define RP_REND 16u    // pin[33010], [33011] = Ctrl.r_end, r_tail
-#define RP_XSUM 32u    // pin[33040..+8)      = the four header sums of the exchange (u64 each)
-__global__ void k_report(Dev d, u32 K, u32 what, u32 *pin, const u64 *xsum) {
+// (pin[33040..+8) = the four header sums of an exchange round, u64 each: written by exchange_finish)
+__global__ void k_report(Dev d, u32 K, u32 what, u32 *pin) {
     const u32 t = threadIdx.x;
     const Ctrl *c = d.ctrl;
     if ((what & RP_STATE) && t < 32) pin[t] = reinterpret_cast<const u32 *>(&c->state[K & 1])[t];
@@ -2031,7 +2032,6 @@ __global__ void k_report(Dev d, u32 K, u32 what, u32 *pin, const u64 *xsum) {
     if ((what & RP_ERR) && t < 8) pin[33020 + t] = c->err[t];
     if ((what & RP_QUEUE) && t == 0) { pin[33008] = c->q_begin; pin[33009] = c->q_tail; }
     if ((what & RP_REND) && t == 0) { pin[33010] = c->r_end; pin[33011] = c->r_tail; }
-    if ((what & RP_XSUM) && t < 8) pin[33040 + t] = reinterpret_cast<const u32 *>(xsum)[t];
 }
 
 // ---- result readback ------------------------------------------------------------------------------------
@@ -2115,10 +2115,10 @@ struct ocrgpu_engine {
     u64 *tiles;                           // OCRGPU_F_WIDE_DB: 64 words per explicit datablock (through Ctrl as well)
     u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
     // comm-platform over RCCL (ocrgpu_comm_*): communicator of this partition, receive regions, a small device word block
-    void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records; u64 *xsum_dev;
+    void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records;
     // peer windows (ocrgpu_peer_*): my window, the device table of everybody's, what was opened from other processes, the round
     // counter every partition advances together, the wait limit in wall-clock ticks; hdr_fresh: the step just queued wrote the headers
-    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> *peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; bool peer_on, hdr_fresh, ahead_timed, end_pending; hipEvent_t ra_ev[2];
+    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; bool peer_on, hdr_fresh, ahead_timed, end_pending; hipEvent_t ra_ev[2];
     u64 *wp; u64 wp_cap, wp_head, wp_tail; // workpile: ring of guids in HBM, indices kept by the (single) caller side
     // reclaimed capacity (ocrgpu_reclaim, ocrgpu_db_destroy): device tables, host mirrors of the free-stack heights and of the
     // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
@@ -2221,8 +2221,8 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     { int sr = scratch_setup(device); if (sr) return sr; } // this GPU's address of the static scratch array (ocrgpu_pop_ready_noalloc)
     ocrgpu_engine *e = new ocrgpu_engine();
     e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
-    e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0; e->xsum_dev = nullptr;
-    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_opened = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false; e->ra_ev[0] = e->ra_ev[1] = nullptr;
+    e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0;
+    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false; e->ra_ev[0] = e->ra_ev[1] = nullptr;
     e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
     memset(&e->rc, 0, sizeof e->rc); e->n_free_edt = e->n_free_evt = e->n_free_db = e->n_held = 0; e->mut_epoch = 0; e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
@@ -2347,7 +2347,6 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     if (e->comm) (void)ocrgpu_comm_fini(e);
     (void)ocrgpu_peer_fini(e);
     if (e->recv_buf) (void)hipFree(e->recv_buf);
-    if (e->xsum_dev) (void)hipFree(e->xsum_dev);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->stage_dev) (void)hipFree(e->stage_dev);
     if (e->scan_partials) (void)hipFree(e->scan_partials);
@@ -2416,7 +2415,7 @@ static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool ti
             launch_step(e, grid, K);
         }
         launched += batch;
-        k_report<<<1, 64, 0, e->stream>>>(d, K - 1, RP_STATE | RP_SENDCNT | RP_ERR, e->pinned_dev, nullptr);
+        k_report<<<1, 64, 0, e->stream>>>(d, K - 1, RP_STATE | RP_SENDCNT | RP_ERR, e->pinned_dev);
         HIPCHK(hipStreamSynchronize(e->stream));
         if (((State *)e->pinned_done)->done) break;
         if (launched >= max_launches) break;
@@ -2451,7 +2450,7 @@ static int check_fault(ocrgpu_engine *e) {
 static int drain_events(ocrgpu_engine *e) {
     if (e->defer_drain) return 0; // distributed stepping: the driver calls ocrgpu_step
     // q_begin, q_tail and err[] sit in different cache lines of Ctrl: three small reads, one sync
-    k_report<<<1, 64, 0, e->stream>>>(e->d, 0u, RP_QUEUE | RP_ERR, e->pinned_dev, nullptr);
+    k_report<<<1, 64, 0, e->stream>>>(e->d, 0u, RP_QUEUE | RP_ERR, e->pinned_dev);
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->pinned_done[33009] > e->pinned_done[33008]) { int r = run_steps(e, 0u, ~0ull, false); if (r) return r; }
     return check_fault(e);
@@ -2865,7 +2864,7 @@ static int pop_ready_args(ocrgpu_engine *e, u64 max_edts, u64 max_deps, u64 *n_e
     if (!n_edts_out || !n_deps_out) FAIL(OCRGPU_EINVAL, "null argument");
     if ((max_edts && (!param0_out || !depc_out || !dep_first_out)) || (max_deps && (!dep_guid_out || !dep_value_out))) FAIL(OCRGPU_EINVAL, "null array");
     if (max_edts > 0xFFFFFFFFull || max_deps > 0xFFFFFFFFull) FAIL(OCRGPU_EINVAL, "capacity above 2^32");
-    k_report<<<1, 64, 0, e->stream>>>(e->d, 0u, RP_REND, e->pinned_dev, nullptr);
+    k_report<<<1, 64, 0, e->stream>>>(e->d, 0u, RP_REND, e->pinned_dev);
     HIPCHK(hipStreamSynchronize(e->stream));
     *r_end_out = e->pinned_done[33010];
     *n_edts_out = 0; *n_deps_out = 0;
@@ -3162,8 +3161,8 @@ extern "C" int ocrgpu_peer_connect(ocrgpu_engine_t *e, const void *handles) {
     if (e->peer_on) FAIL(OCRGPU_EINVAL, "already connected");
     Dev &d = e->d;
     std::vector<char *> base(d.n_loc, nullptr);
-    std::vector<void *> *opened = new std::vector<void *>();
-    auto undo = [&]() { for (void *q : *opened) (void)hipIpcCloseMemHandle(q); delete opened; };
+    std::vector<void *> opened;
+    auto undo = [&]() { for (void *q : opened) (void)hipIpcCloseMemHandle(q); };
     for (u32 p = 0; p < d.n_loc; ++p) {
         PeerHandle h; memcpy(&h, (const char *)handles + (size_t)p * OCRGPU_PEER_HANDLE_BYTES, sizeof h);
         if (h.n_loc != d.n_loc || h.send_cap != d.send_cap || h.location != p || h.bytes != e->peer_win_bytes) {
@@ -3178,7 +3177,7 @@ extern "C" int ocrgpu_peer_connect(ocrgpu_engine_t *e, const void *handles) {
         void *q = nullptr;
         hipError_t er = hipIpcOpenMemHandle(&q, h.ipc, hipIpcMemLazyEnablePeerAccess);
         if (er != hipSuccess) { (void)hipGetLastError(); undo(); FAIL(OCRGPU_EHIP, "hipIpcOpenMemHandle of location %u's window: %s", p, hipGetErrorString(er)); }
-        opened->push_back(q); base[p] = (char *)q;
+        opened.push_back(q); base[p] = (char *)q;
     }
     if (!e->peer_base_dev) { int r = dalloc(e, (void **)&e->peer_base_dev, 8 * 1024); if (r) { undo(); return r; } }
     { int r = xchg_words(e); if (r) { undo(); return r; } }
@@ -3188,14 +3187,15 @@ extern "C" int ocrgpu_peer_connect(ocrgpu_engine_t *e, const void *handles) {
     HIPCHK(hipStreamSynchronize(e->stream));
     const char *ms = getenv("OCRGPU_PEER_TIMEOUT_MS");
     e->peer_limit = 100000ull * (u64)(ms && atoi(ms) > 0 ? atoi(ms) : 2000); // 100 MHz ticks
-    e->peer_opened = opened; e->peer_round = 0; e->peer_on = true;
+    e->peer_opened.swap(opened); e->peer_round = 0; e->peer_on = true;
     return 0;
 }
 extern "C" int ocrgpu_peer_fini(ocrgpu_engine_t *e) {
     if (!e) FAIL(OCRGPU_EINVAL, "null engine");
     if (!e->peer_win && !e->peer_on) return 0;
     (void)hipSetDevice(e->device); (void)hipStreamSynchronize(e->stream);
-    if (e->peer_opened) { for (void *q : *e->peer_opened) (void)hipIpcCloseMemHandle(q); delete e->peer_opened; e->peer_opened = nullptr; }
+    for (void *q : e->peer_opened) (void)hipIpcCloseMemHandle(q);
+    e->peer_opened.clear();
     if (e->peer_win) { (void)hipFree(e->peer_win); e->peer_win = nullptr; }
     e->peer_on = false;
     return 0;
