@@ -1177,7 +1177,8 @@ __global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) { begin_
 #define RA_ACT 1030u    // (u64, 8-byte aligned) activity of the level so far
 #define RA_ROUND 1032u  // rounds applied since k_ra_init
 #define RA_STOP_AT 1033u // 1 + the round in which RA_STOP was set (what the host goes by: see resolve_run_ahead)
-__global__ void k_ra_init(u32 *w) { w[RA_STOP] = 0; w[RA_HOLD] = 0; w[RA_LEVELS] = 0; w[RA_KIND] = 0; w[RA_ACT] = 0; w[RA_ACT + 1] = 0; w[RA_ROUND] = 0; w[RA_STOP_AT] = 0; }
+#define RA_BEHIND 1034u  // a NO_CASCADE run was stopped because a partition had fallen a level behind
+__global__ void k_ra_init(u32 *w) { w[RA_STOP] = 0; w[RA_HOLD] = 0; w[RA_LEVELS] = 0; w[RA_KIND] = 0; w[RA_ACT] = 0; w[RA_ACT + 1] = 0; w[RA_ROUND] = 0; w[RA_STOP_AT] = 0; w[RA_BEHIND] = 0; }
 __device__ __forceinline__ void begin_auto(const Dev &d, u32 K0, u32 *w) {
     u32 fire = 0, force = 0;
     if (w[RA_STOP]) w[RA_KIND] = 2;
@@ -1747,7 +1748,7 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
     // early.  (With settle rounds every queue is empty when a level fires.)  The host-driven loop finishes such a step with polls
     // before the exchange; rounds queued ahead cannot, and stop with an error instead of mislabelling.
     const u32 behind = (u32)(sum[3] >> 40);
-    if (!late && kind == 1u && no_cascade && behind != 0u && behind != n_src) { ra[RA_STOP] = 1; pin[PIN_RA + 2] = 0xBAD0BAD0u; }
+    if (!late && kind == 1u && no_cascade && behind != 0u && behind != n_src) { ra[RA_STOP] = 1; ra[RA_BEHIND] = 1; }
     if (late) ra[RA_STOP] = 1;
     else if (kind != 2u) {
         u64 act = *reinterpret_cast<u64 *>(&ra[RA_ACT]) + sum[1];
@@ -1757,7 +1758,7 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
     }
     const u32 round_no = ra[RA_ROUND]; ra[RA_ROUND] = round_no + 1;
     if (ra[RA_STOP] && !ra[RA_STOP_AT]) ra[RA_STOP_AT] = round_no + 1;
-    pin[PIN_RA + 1] = ra[RA_LEVELS]; if (pin[PIN_RA + 2] != 0xBAD0BAD0u) pin[PIN_RA + 2] = ra[RA_HOLD]; pin[PIN_RA + 3] = round_no + 1;
+    pin[PIN_RA + 1] = ra[RA_LEVELS]; pin[PIN_RA + 2] = ra[RA_BEHIND] ? 0xBAD0BAD0u : ra[RA_HOLD]; pin[PIN_RA + 3] = round_no + 1; // (stores only: nothing is read back over PCIe)
     pin[PIN_RA] = ra[RA_STOP_AT]; // 0 = still running; else 1 + the round that ended the run
     if (next_K0) begin_auto(d, next_K0, ra);
 }
