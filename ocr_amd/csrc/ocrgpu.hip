@@ -657,16 +657,28 @@ __device__ __forceinline__ ulonglong2 db_gather(const Dev &d, u32 p) {
 }
 
 // queue a satisfy for another partition: per-destination send buffer, DB shipped by value
+// AGG: the reservation is shared by the lanes of the wavefront (below).  Only the fan-out asks for it, and not in the tile-body
+// instantiation of k_step (tile engines have one partition; the code inlined there cost it 70 VGPRs and a wave of occupancy).
+template <bool AGG> __device__ __forceinline__ void emit_remote_record(const Dev &d, u64 guid, u32 slot, u32 xflags, u64 value, u64 tag);
+template <bool AGG = false>
 __device__ __forceinline__ void emit_remote(const Dev &d, u64 guid, u32 slot, u32 xflags, u32 payload) {
     u32 loc = OCRGPU_GUID_LOCATION(guid);
     if (d.send == nullptr || loc >= d.n_loc) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
     ulonglong2 b = make_ulonglong2(0, 0);
     if (payload && !(xflags & XF_MODE_NULL)) { b = db_gather(d, payload); xflags |= XF_HAS_DB; }
-    emit_remote_raw(d, guid, slot, xflags, b.x, b.y);
+    emit_remote_record<AGG>(d, guid, slot, xflags, b.x, b.y);
 }
-__device__ void emit_remote_raw(const Dev &d, u64 guid, u32 slot, u32 xflags, u64 value, u64 tag) {
+__device__ void emit_remote_raw(const Dev &d, u64 guid, u32 slot, u32 xflags, u64 value, u64 tag) { emit_remote_record<false>(d, guid, slot, xflags, value, tag); }
+template <bool AGG>
+__device__ __forceinline__ void emit_remote_record(const Dev &d, u64 guid, u32 slot, u32 xflags, u64 value, u64 tag) {
     u32 loc = OCRGPU_GUID_LOCATION(guid);
     if (d.send == nullptr || loc >= d.n_loc) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
+    if (!AGG) {
+        const u32 pos1 = atomicAdd(&d.send_cnt[loc * 32], 1u);
+        if (pos1 + 1 >= d.send_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // (the last slot of a region is its header)
+        d.send[(size_t)loc * d.send_cap + pos1] = SendRec{guid, slot, xflags, value, tag};
+        return;
+    }
     // The lanes of this wavefront that are here together with the same destination take ONE atomic on its counter (a level of the
     // bench's DAG queues ~5000 records per destination; one atomic each on a single word took 110 us of the launch), and the
     // atomics of the different destinations go out TOGETHER: the groups are found first (ballots, no memory), then the lowest
@@ -694,7 +706,7 @@ __device__ void emit_remote_raw(const Dev &d, u64 guid, u32 slot, u32 xflags, u6
 // consecutive entries of the ready log up front (one atomic, issued before the waiter loads so it costs no
 // extra round trip) and lane t writes entry t: the EDT it made ready, or INVALID.  Compaction happens on
 // the read side (the FIRE pass skips holes), where it is a ballot instead of a dependent atomic.
-template <bool NANNY, bool LOCKABLE>
+template <bool NANNY, bool LOCKABLE, bool TILES>
 __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 total, u32 *lds_base, u64 &n_edt_sat, u64 &n_evt_sat) {
     Ctrl *c = d.ctrl;
     u32 rbase = 0;
@@ -724,7 +736,7 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         if (__ballot(is_latch)) latch_issue(d, is_latch, dst, slot, l_lead, l_old, l_delta);
         if (act) {
             if (flags & RF_DST_EDT) ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, dst, slot, payload, flags);
-            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote(d, rd.guid, rd.slot, rd.flags, payload); }
+            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote<!TILES>(d, rd.guid, rd.slot, rd.flags, payload); }
         }
         // statistics are wave totals (one ballot each), so the epilogue needs no cross-lane reduction
         n_edt_sat += __popcll(__ballot(act && (flags & RF_DST_EDT))); n_evt_sat += __popcll(__ballot(to_evt));
@@ -1082,7 +1094,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             seg[threadIdx.x] = sg;
             lds_barrier();
             STAMP(2);
-            if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
+            if (total) fan_out<NANNY, LOCKABLE, TILES>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             STAMP(3);
             if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST && OCRBODY_KIND(body) != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb);
             if (TILES) tile_bodies_wave(d, mine && !defer && OCRBODY_KIND(body) == OCRBODY_TILE, e, tt);
@@ -1126,7 +1138,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             sg.end_off = incl;
             seg[threadIdx.x] = sg;
             lds_barrier();
-            if (total) fan_out<NANNY, LOCKABLE>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
+            if (total) fan_out<NANNY, LOCKABLE, TILES>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
         }
     }
     if (owed && part == gridDim.x) deferred_bodies<TILES>(d, P.b_begin, P.b_end, blockIdx.x, gridDim.x); // no idle workgroup in this launch

@@ -144,6 +144,7 @@ def run(spec, steps=3, warmup=1, parity=True):
             out["parity"] = "bit-exact vs CPU restatement" if not diff else f"MISMATCH {diff[:3]}"
         out["restatement_s"] = round(time.time() - t0, 2)
     print(json.dumps(out), flush=True)
+    eng.close()          # free the gigabytes NOW: left to the garbage collector, the hipFree lands in the next workload's timed loop
     del prog, eng
     return out
 
