@@ -38,6 +38,41 @@ def test_windows_in_one_process_are_partition_invariant(name, world):
     assert res.diff(O.run_restatement(s)) == []
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("name", ["layered_100k", "powerlaw_100k"])
+def test_large_streams_over_windows(name, world):
+    """100 000 EDTs over 2 / 4 / 8 partitions, rounds queued ahead: the power-law DAG has latches chained across partitions
+    (arrivals fire events that send on: settle rounds, decided on the device), the layered one fills the regions"""
+    s = ALL[name]
+    parts = D.build_lockstep([D.Partition(s, r, world) for r in range(world)])
+    D.connect_peer_windows(parts)
+    levels = D.resolve_lockstep_c(parts)
+    res = D.gather_result_lockstep(s, parts)
+    errs = [list(p.eng.stats().err) for p in parts]
+    for p in parts:
+        p.eng.close()
+    want = O.run_restatement(s)
+    assert all(sum(e) == 0 for e in errs), errs
+    assert res.diff(want) == [] and levels == int(want.level.max()) + 1
+
+
+@pytest.mark.parametrize("G,steps,world", [(16, 10, 8), (64, 6, 4)])
+def test_stencil_blocks_over_windows(G, steps, world):
+    """config 4's placement (blocks of tiles per partition, only halo edges cross) with the C loop over the windows"""
+    from ocr_amd.opstream import stencil_dag
+    s = ALL["stencil_16x16x10"] if (G, steps) == (16, 10) else stencil_dag(G, steps)
+    own = D.stencil_block_owner(G, steps, world)
+    parts = D.build_lockstep([D.Partition(s, r, world, owner_edt=own) for r in range(world)])
+    D.connect_peer_windows(parts)
+    D.resolve_lockstep_c(parts)
+    res = D.gather_result_lockstep(s, parts)
+    errs = [list(p.eng.stats().err) for p in parts]
+    for p in parts:
+        p.eng.close()
+    assert all(sum(e) == 0 for e in errs), errs
+    assert res.diff(O.run_restatement(s)) == []
+
+
 @pytest.mark.parametrize("mode", ["budget1", "budget2_ahead1", "ahead3", "host_driven", "host_driven_budget1"])
 @pytest.mark.parametrize("name", ["layered_1k", "event_chain", "counted_events", "channel_events", "cholesky_T8", "wide_fanin",
                                   "sticky_early_and_late"])
