@@ -402,7 +402,7 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     dist.destroy_process_group()
 
 
-PROFILE_TAG = "r02i_config2"
+PROFILE_TAG = "r02j_config2"
 
 
 def profiled_traffic(args, tag=PROFILE_TAG):

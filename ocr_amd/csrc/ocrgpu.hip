@@ -1742,9 +1742,11 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
         if (cnt > stride - 1) cnt = stride - 1;
         for (u64 k = part * (u64)blockDim.x + threadIdx.x; k < cnt; k += per * (u64)blockDim.x) apply_record(d, recs[(u64)s * stride + k], db_floor);
     }
-    __threadfence();
+    // (every wave waits for its own stores, the barrier joins them, ONE lane releases for the workgroup at device scope: a release is
+    // cumulative over what happens before it, and a fence per wave -- each a write-back of the L2 -- was most of this kernel's tail)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (threadIdx.x == 0) { last = atomicAdd(&words[1025], 1u) == gridDim.x - 1 ? 1u : 0u; if (last) words[1025] = 0; }
+    if (threadIdx.x == 0) { __threadfence(); last = atomicAdd(&words[1025], 1u) == gridDim.x - 1 ? 1u : 0u; if (last) { words[1025] = 0; __threadfence(); } }
     __syncthreads();
     if (!last) return;
     __shared__ unsigned long long sum[4];
@@ -1803,9 +1805,12 @@ __global__ void k_peer_push(Dev d, PeerDev pd, u64 round, u32 K, u32 end) {
     }
     // Every workgroup releases its stores at SYSTEM scope before it is counted (fence - atomic - atomic - fence: the last workgroup's
     // fence in front of the arrival word then orders everybody's records before it, for an observer on another GPU too).  Such a
-    // fence writes the L2 back each time, which is why a destination gets few workgroups when there are many destinations.
-    __threadfence_system();
+    // fence writes the L2 back each time, which is why a destination gets few workgroups when there are many destinations, and why
+    // ONE lane issues it for the workgroup: the waves wait for their own stores (workgroup scope), the barrier joins them, and a
+    // release is cumulative over everything that happens before it.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    if (threadIdx.x == 0) __threadfence_system();
     if (threadIdx.x == 0 && atomicAdd(&pd.cnt[p], 1u) == per_dest - 1) { // the last of p's workgroups: everybody's stores are out
         pd.cnt[p] = 0;
         __threadfence_system();
