@@ -388,7 +388,8 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
             "config": {"workload": f"layered random DAG, {N} EDTs in {N // width} layers of {width} ({args.n_edt} EDTs per GPU), "
                                    f"depc=1+popcount(6 bits) (mean 4), ONCE output events, HASH bodies, latch+sink; GUID space "
                                    f"partitioned round-robin over {world} GPUs, cross-partition satisfies exchanged per level by {backend}",
-                       "n_edt": N + 1, "n_satisfactions": n_sat, "levels": int(levels),
+                       "n_edt": N + 1, "n_satisfactions": n_sat, "levels": int(levels), "transport": transport,
+                       "us_per_level": round(dt / args.steps / max(int(levels), 1) * 1e6, 1),
                        "edts_fired_per_s": (N + 1) / (dt / args.steps), "build_s": round(build_s, 2),
                        "parity": "every EDT fired at the level of its layer on every rank; partition invariance vs the "
                                  "single-partition oracle is proven by tests/test_gpu_partitioned.py and test_gpu_workload_partition.py"},
