@@ -60,6 +60,18 @@ def build_program(src, name=None, force=False, defines=()):
     return out
 
 
+def build_cabi_host(src, name=None, force=False):
+    """Compile a plain C host of libocrgpu (no shim, no OCR headers): ocr_amd/bin/<name>."""
+    build_lib()
+    os.makedirs(PROG_DIR, exist_ok=True)
+    out = os.path.join(PROG_DIR, name or os.path.splitext(os.path.basename(src))[0])
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(p) for p in [src, LIB] + HDRS):
+        return out
+    subprocess.check_call(["gcc", "-O2", "-g", "-std=gnu11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", HERE, "-locrgpu",
+                           "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath-link,/opt/rocm/lib", "-o", out])
+    return out
+
+
 if __name__ == "__main__":
     print(build_lib(force=True))
     print(build_shim(force=True))
