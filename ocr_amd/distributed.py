@@ -360,8 +360,15 @@ def connect_peer_windows(parts):
 
 def connect_peer_windows_dist(part, dist, group=None):
     """One partition per process: the window handles travel over the process group (plain bytes, any backend will do)."""
+    try:
+        mine, why = part.eng.peer_export(), None
+    except Exception as ex:  # noqa: BLE001 -- every rank still takes part in the collective below, or the others would wait for it
+        mine, why = None, ex
     handles = [None] * dist.get_world_size(group)
-    dist.all_gather_object(handles, part.eng.peer_export(), group=group)
+    dist.all_gather_object(handles, mine, group=group)
+    if any(h is None for h in handles):
+        raise RuntimeError(f"peer windows: rank(s) {[r for r, h in enumerate(handles) if h is None]} could not export a window"
+                           + (f" (here: {why})" if why else ""))
     part.eng.peer_connect(handles)
 
 
