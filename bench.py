@@ -226,8 +226,15 @@ def c_transport_up(part, torch, dist, rank, world):
         if rank == 0:
             print(f"[bench] {world} ranks on devices {devs}: ranks share a GPU, the exchange stays on gloo", file=sys.stderr)
         return False
-    uid = [engine.comm_get_unique_id() if rank == 0 else None]
+    uid = [None]
+    if rank == 0:
+        try:
+            uid = [engine.comm_get_unique_id()]
+        except Exception as ex:  # noqa: BLE001 -- rank 0 still broadcasts (None), or the others would wait for it
+            print(f"[bench] no RCCL unique id ({type(ex).__name__}: {str(ex)[:200]})", file=sys.stderr)
     dist.broadcast_object_list(uid, src=0)                   # 128 bytes over gloo: the out-of-band channel
+    if uid[0] is None:
+        return False
     try:
         part.eng.comm_init(uid[0], rank, world)
         src = (torch.arange(world * 1024, dtype=torch.int64, device="cuda") + 1_000_000 * rank)
