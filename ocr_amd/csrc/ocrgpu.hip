@@ -43,19 +43,19 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_
        ERR_Q_OVERFLOW = 5, ERR_LEVEL_OVERFLOW = 6 };
 #define RF_DST_EDT 1u   // record / waiter destination is an EDT pre-slot
 #define RF_MODE_NULL 2u // dependence mode DB_MODE_NULL: the payload is dropped (hc-task.c:1255)
-#define RF_INLINE 4u    // EDT destination: the pre-slot word lives in the EDT's own 64-B line (depc <= 6)
+#define RF_INLINE 4u    // EDT destination: the pre-slot word lives in the EDT's own 64-B line (depc <= 5)
 #define RF_PREFILLED 8u // EDT destination: the payload was already written at registration (static payload)
 #define RF_FIRED 16u    // record only: the event already fired (its satisfy logic ran inline), just fan out
 #define RF_PIECE 32u    // record only: fan out piece `slot` (BIG_ROW edges) of the fired event's row
 #define RF_CHANGEN 128u // record only (with RF_FIRED): a CHANNEL pairing; `slot` = index in waiters[] of the waiter that takes `payload`
 #define RF_LAZYWALK 64u // record only: pre-slot `slot` of frontier-tracked EDT `dst` was satisfied -> lazy_walk()
 #define RF_ACQUIRE 256u // record only (Lockable datablocks): EDT `dst` goes on acquiring its datablocks -> acq_walk()
-#define INLINE_SLOTS 6u
+#define INLINE_SLOTS 5u
 #define SLOT_MARK 0x80000000u  // pre-slot word: the slot has been satisfied
 #define PEND_LAZY 0x40000000u  // EdtLine.pending: a COUNTED event sits on a pre-slot the frontier has not reached -> track the frontier
 #define PEND_ACQ 0x20000000u   // EdtLine.pending: Lockable datablocks -- the EDT acquires its datablocks before it is scheduled
 #define PEND_MASK 0x1FFFFFFFu
-// EdtLine.pending of an EDT whose pre-slots live in its line (depc <= 6): bits 0..7 = unsatisfied pre-slots, bit 8+k = pre-slot k
+// EdtLine.pending of an EDT whose pre-slots live in its line (depc <= 5): bits 0..7 = unsatisfied pre-slots, bit 8+k = pre-slot k
 // has been satisfied.  The satisfier's ONE atomic adds (1 << (8+k)) - 1: it counts the slot down and marks it, so the frontier
 // walk of lazily registered COUNTED events (hc-task.c:1286-1338) can tell a satisfied pre-slot whose payload word was written
 // at registration (RF_PREFILLED: the satisfy stores nothing) from an unsatisfied one.  EDTs with more pre-slots keep a plain
@@ -74,13 +74,19 @@ enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_
 struct EvtRec { u32 row_begin, deg, state_kind; s32 val; };
 // One EDT = one 64-B line: everything a satisfy or a fire touches for this EDT shares a sector -- the pending
 // counter the atomics hit, the record the firing lane reads, the ONCE output event (event index max_evt+e)
-// and up to 6 pre-slot payload words.  EDTs with depc > 6 keep their slot words in `slots[slot_ovf..]`.
+// and up to 5 pre-slot payload words.  EDTs with depc > 5 keep their slot words in `slots[slot_ovf..]`.
+// {pending, level} is ONE aligned 8-byte word: the barrier-free resolve (k_async) counts a pre-slot down with a 64-bit returning
+// add that brings the level back with the count.  {val, out_state, body} is ONE aligned 16-byte granule: a body publishes its
+// value and BODY_VAL_DONE with one store, so a consumer that reads the granule in one load never pairs a flag with an old value.
 struct alignas(64) EdtLine {
-    u32 pending, depc, body, out_state;   // out_state: state | kind<<8 of the ONCE output event
-    u64 param0, val;                      // paramv[0]; the body's fold (== value of the output DB)
+    u32 pending, level;                   // level: 1 + the highest level among the EDTs that satisfied a pre-slot so far (k_async only)
+    u64 param0;                           // paramv[0]
+    u64 val; u32 out_state, body;         // the body's fold (== value of the output DB); state | kind<<8 of the ONCE output event
     u32 out_row, out_deg;                 // CSR row of the output event's waiters
-    u32 slot[INLINE_SLOTS];               // depc <= 6: the pre-slot words; else slot[0] = base index into `slots`
+    u32 depc;
+    u32 slot[INLINE_SLOTS];               // depc <= 5: the pre-slot words; else slot[0] = base index into `slots`
 };
+#define BODY_VAL_DONE 0x20000000u // EdtLine.body: the built-in body has run, `val` is final
 static_assert(sizeof(EdtLine) == 64, "EdtLine must be one 64-byte sector");
 struct Rec { u32 dst, payload, slot, flags; };      // one pending satisfy: dst = event idx | EDT idx
 // CHANNEL event (hc-event.c:2081-2156): generation k pairs the k-th satisfy with the k-th registered waiter.  Two rings of
@@ -142,7 +148,7 @@ struct Dev {
     Ctrl *ctrl;
     // EDTs
     EdtLine *edt; u32 *edt_script_begin, *edt_script_len;
-    u32 *slots;                 // overflow pre-slot words (depc > 6): dbidx+1 (0 = NULL_GUID); bit31 = satisfied (nanny)
+    u32 *slots;                 // overflow pre-slot words (depc > 5): dbidx+1 (0 = NULL_GUID); bit31 = satisfied (nanny)
     // events: explicit [0,max_evt) in `evt`; the output event of EDT e is event max_evt+e and lives in edt[e]
     EvtRec *evt;
     u64 *counted;               // COUNTED events: the accounting word (CNT_SAT | left << 32 | lazy pending), see counted_*();
@@ -310,7 +316,7 @@ template <bool NANNY, bool LOCKABLE>
 __device__ __forceinline__ bool edt_slot_satisfy(const Dev &d, const Step &S, u32 edt, u32 slot, u32 payload, u32 flags) {
     EdtLine *L = &d.edt[edt];
     u32 word = (flags & RF_MODE_NULL) ? 0u : payload;
-    // overflow pre-slots (depc > 6): `slot` is relative, the base sits in the line the atomic is about to touch
+    // overflow pre-slots (depc > 5): `slot` is relative, the base sits in the line the atomic is about to touch
     const bool inl = (flags & RF_INLINE) != 0;
     if (NANNY) {
         u32 *sp = inl ? &L->slot[slot] : &d.slots[(size_t)L->slot[0] + slot];
@@ -652,8 +658,8 @@ struct Seg { u32 row, end_off, payload; }; // end_off = inclusive prefix sum of 
 __device__ __forceinline__ ulonglong2 db_gather(const Dev &d, u32 p) {
     if (p == 0) return make_ulonglong2(0, ~0ULL);
     if (p - 1 < d.max_db) return d.db[p - 1];
-    const ulonglong2 pv = *reinterpret_cast<const ulonglong2 *>(&d.edt[p - 1 - d.max_db].param0);
-    return make_ulonglong2(pv.y, d.hash_tag_base + pv.x);
+    const EdtLine *P = &d.edt[p - 1 - d.max_db];
+    return make_ulonglong2(P->val, d.hash_tag_base + P->param0);
 }
 
 // queue a satisfy for another partition: per-destination send buffer, DB shipped by value
@@ -792,7 +798,8 @@ __device__ __forceinline__ u32 block_inclusive_scan(u32 v, u32 *wave_sums, u32 &
 }
 
 // the body proper: fold id + every depv[k] payload (8 pre-slots per round of loads; gb = the first round, already loaded)
-__device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, const u32 *sl, ulonglong2 (&gb)[8]) {
+// value, output-event state and body word go out as ONE 16-byte store (`ostate` / `body`: what the line holds for them now)
+__device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, const u32 *sl, ulonglong2 (&gb)[8], u32 ostate, u32 body) {
     u64 v = ocrops_hash_init(id);
     for (u32 k0 = 0; k0 < depc; k0 += 8) {
         if (k0) {
@@ -802,7 +809,7 @@ __device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, 
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (k0 + k < depc) v = ocrops_hash_step(v, k0 + k, gb[k].x, gb[k].y + 1);
     }
-    d.edt[e].val = v; // == the output DB's value (a live DB only for HASH bodies)
+    *reinterpret_cast<uint4 *>(&d.edt[e].val) = make_uint4((u32)v, (u32)(v >> 32), ostate, body | BODY_VAL_DONE); // val == the output DB's value (a live DB only for HASH bodies)
 }
 
 // OCRBODY_TILE (8x8 int64 tiles updated in place by integer recurrences): the pre-slots that carry a datablock
@@ -869,8 +876,8 @@ __device__ __forceinline__ void deferred_body(const Dev &d, u32 e, bool &tile, u
     const u32 *sl; u32 pw[8]; ulonglong2 gb[8];
     if (L.depc <= INLINE_SLOTS) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) pw[k] = L.slot[k] & 0x7FFFFFFFu;
-        pw[6] = pw[7] = 0; sl = d.edt[e].slot;
+        for (int k = 0; k < (int)INLINE_SLOTS; ++k) pw[k] = L.slot[k] & 0x7FFFFFFFu;
+        pw[5] = pw[6] = pw[7] = 0; sl = d.edt[e].slot;
     } else {
         sl = d.slots + L.slot[0];
 #pragma unroll
@@ -879,7 +886,7 @@ __device__ __forceinline__ void deferred_body(const Dev &d, u32 e, bool &tile, u
     if (TILES && OCRBODY_KIND(L.body) == OCRBODY_TILE) { tile = true; tile_operands(pw, L.depc, tt); return; }
 #pragma unroll
     for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
-    run_body(d, e, L.param0, L.depc, sl, gb);
+    run_body(d, e, L.param0, L.depc, sl, gb, L.out_state, L.body);
 }
 template <bool TILES>
 __device__ void deferred_bodies(const Dev &d, u32 b_begin, u32 b_end, u32 h, u32 nh) {
@@ -1023,15 +1030,15 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (i < S.r_end) e = d.fired[i];
             const bool mine = e != INVALID;
             bool epi = false;
-            u32 body = 0, depc = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr; ulonglong2 gb[8]; u32 tt[3] = {0, 0, 0};
+            u32 body = 0, depc = 0, ostate = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr; ulonglong2 gb[8]; u32 tt[3] = {0, 0, 0};
             if (mine) {
                 const EdtLine L = d.edt[e]; // the one 64-B read that carries everything this EDT needs to fire
-                body = L.body; depc = L.depc; id = L.param0;
+                body = L.body; depc = L.depc; id = L.param0; ostate = L.out_state;
                 const u32 x = d.max_evt + e;
                 if (depc <= INLINE_SLOTS) {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) pw[k] = L.slot[k] & 0x7FFFFFFFu;
-                    pw[6] = pw[7] = 0; sl = d.edt[e].slot;
+                    for (int k = 0; k < (int)INLINE_SLOTS; ++k) pw[k] = L.slot[k] & 0x7FFFFFFFu;
+                    pw[5] = pw[6] = pw[7] = 0; sl = d.edt[e].slot;
                 } else {
                     sl = d.slots + L.slot[0];
 #pragma unroll
@@ -1049,7 +1056,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                 // With other partitions around, a satisfy may carry this EDT's output DB away by value in this very
                 // launch, so the body runs first; on a single partition it runs after the fan-out (off the critical path).
                 const bool host_body = kind == OCRBODY_HOST; // taskExecute happens on the host (ocrgpu_pop_ready)
-                if (body_first && !host_body && kind != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb); // (tile datablocks: one partition only)
+                if (body_first && !host_body && kind != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, ostate, body); // (tile datablocks: one partition only)
                 if (body & BODY_F_SCRIPT) { // the body's own ocrEventSatisfySlot / ocrEventDestroy calls
                     u32 sb = d.edt_script_begin[e], sn = d.edt_script_len[e];
                     for (u32 k = 0; k < sn; ++k) {
@@ -1083,6 +1090,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                     bool ok = true;
                     if (NANNY) ok = evt_satisfy_simple(d, x, OCREVT_ONCE, ret);
                     else d.edt[e].out_state = ST_DESTROYED | (OCREVT_ONCE << 8); // only its own EDT satisfies it
+                    ostate = ST_DESTROYED | (OCREVT_ONCE << 8);
                     if (ok && !split_big_row(d, S, x, L.out_deg, ret)) { deg = L.out_deg; sg.row = L.out_row; sg.payload = ret; }
                 }
             }
@@ -1096,7 +1104,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             STAMP(2);
             if (total) fan_out<NANNY, LOCKABLE, TILES>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             STAMP(3);
-            if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST && OCRBODY_KIND(body) != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb);
+            if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST && OCRBODY_KIND(body) != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, ostate, body);
             if (TILES) tile_bodies_wave(d, mine && !defer && OCRBODY_KIND(body) == OCRBODY_TILE, e, tt);
         }
     } else {
@@ -1305,13 +1313,13 @@ __global__ void k_edt_create(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n, c
     if (i >= n) return;
     u32 e = take_index(rc.free_edt, n_free, n_take, first_idx, i), dc = depc[i], b = body[i] & 0xFFFFu;
     EdtGuids eg = {0, 0, 0, 0};
-    if ((OCRBODY_KIND(b) == OCRBODY_TILE && (dc > INLINE_SLOTS || !d.ctrl->tiles)) || (d.ctrl->dbl && dc > LOCKABLE_MAX_DEPC)) { // a TILE body reads its (<= 6) pre-slots from the line, and needs tile datablocks // acq_walk / release_all are quadratic in depc: refuse what would not finish (the EDT does not exist)
+    if ((OCRBODY_KIND(b) == OCRBODY_TILE && (dc > INLINE_SLOTS || !d.ctrl->tiles)) || (d.ctrl->dbl && dc > LOCKABLE_MAX_DEPC)) { // a TILE body reads its (<= 5) pre-slots from the line, and needs tile datablocks // acq_walk / release_all are quadratic in depc: refuse what would not finish (the EDT does not exist)
         atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); EdtLine Z; memset(&Z, 0, sizeof Z); Z.out_state = (u32)ST_ABSENT; d.edt[e] = Z; rc.edt_guids[e] = eg;
         if (!gin) { guids_out[i] = 0; if (outevt_out) outevt_out[i] = 0; if (outdb_out) outdb_out[i] = 0; }
         return;
     }
     EdtLine L;
-    L.pending = dc | ((d.ctrl->dbl && dc) ? PEND_ACQ : 0u); L.depc = dc; L.body = b;
+    L.pending = dc | ((d.ctrl->dbl && dc) ? PEND_ACQ : 0u); L.level = 0; L.depc = dc; L.body = b;
     L.param0 = param0 ? param0[i] : (u64)e; L.val = 0;
     L.out_row = 0; L.out_deg = 0;
     L.out_state = (b & OCRBODY_F_OUTEVT) ? (ST_LIVE | (OCREVT_ONCE << 8)) : (u32)ST_ABSENT; // ONCE output event (hc-task.c:940-959)
@@ -1943,8 +1951,9 @@ __global__ void k_reclaim_lazy_users(Dev d, ReclDev rc, u32 n_edt) {
     u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     bool live = false;
     if (e < n_edt) {
-        const uint4 h = *reinterpret_cast<const uint4 *>(&d.edt[e]); // pending, depc, body, out_state
-        live = !(h.z & BODY_FREE) && (h.x & PEND_LAZY) && (h.x & (h.y <= INLINE_SLOTS ? PEND_INL_CNT : PEND_MASK)) != 0;
+        const EdtLine *L = &d.edt[e];
+        const u32 pd = L->pending;
+        live = !(L->body & BODY_FREE) && (pd & PEND_LAZY) && (pd & (L->depc <= INLINE_SLOTS ? PEND_INL_CNT : PEND_MASK)) != 0;
     }
     const u64 m = __ballot(live);
     if (m && lane_id() == (u32)(__ffsll((long long)m) - 1)) atomicAdd(&rc.cnt[RC_LAZY_LIVE], (u32)__popcll(m));
@@ -1959,8 +1968,8 @@ __global__ void k_reclaim_edts(Dev d, ReclDev rc, u32 n_held, u32 r_end, u32 pop
     const bool from_log = i >= n_held;
     const u32 e = from_log ? d.fired[i - n_held] : rc.held[i];
     if (e == INVALID) return;
-    const uint4 h = *reinterpret_cast<const uint4 *>(&d.edt[e]);
-    const u32 pending = h.x, body = h.z, out_state = h.w, kind = OCRBODY_KIND(body);
+    EdtLine *L = &d.edt[e];
+    const u32 pending = L->pending, body = L->body, out_state = L->out_state, kind = OCRBODY_KIND(body);
     if (body & BODY_FREE) return;
     if (kind == OCRBODY_HOST && from_log && i - n_held >= pop_cursor) { unpopped[atomicAdd(&rc.cnt[RC_UNPOPPED], 1u)] = e; return; }
     bool ok = true;
@@ -1974,7 +1983,7 @@ __global__ void k_reclaim_edts(Dev d, ReclDev rc, u32 n_held, u32 r_end, u32 pop
     if (g.odb) gtab_remove(d, g.odb);
     rc.edt_guids[e] = EdtGuids{0, 0, 0, 0};
     if (pending & PEND_LAZY) atomicAdd(&rc.cnt[RC_LAZY_FREED], 1u);
-    *reinterpret_cast<uint4 *>(&d.edt[e]) = make_uint4(0u, h.y, BODY_FREE, (u32)ST_ABSENT);
+    L->pending = 0u; L->level = 0u; L->body = BODY_FREE; L->out_state = (u32)ST_ABSENT;
     rc.free_edt[n_free + atomicAdd(&rc.cnt[RC_EDT], 1u)] = e;
 }
 // destructEventHc (hc-event.c:185-242): a destroyed event's record and guid go back
@@ -1992,8 +2001,8 @@ __global__ void k_reclaim_pool_users(Dev d, ReclDev rc, u32 n_edt) {
     u32 e = blockIdx.x * blockDim.x + threadIdx.x;
     bool ovf = false, scr = false;
     if (e < n_edt) {
-        const uint4 h = *reinterpret_cast<const uint4 *>(&d.edt[e]);
-        if (!(h.z & BODY_FREE)) { ovf = h.y > INLINE_SLOTS; scr = (h.z & BODY_F_SCRIPT) != 0; }
+        const u32 bw = d.edt[e].body;
+        if (!(bw & BODY_FREE)) { ovf = d.edt[e].depc > INLINE_SLOTS; scr = (bw & BODY_F_SCRIPT) != 0; }
     }
     const u64 mo = __ballot(ovf), ms = __ballot(scr);
     if (lane_id() == 0) { if (mo) atomicAdd(&rc.cnt[RC_OVF_LIVE], (u32)__popcll(mo)); if (ms) atomicAdd(&rc.cnt[RC_SCRIPT_LIVE], (u32)__popcll(ms)); }
