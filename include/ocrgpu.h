@@ -83,6 +83,10 @@ typedef struct {
  * list is dealt over, default 256), OCRGPU_STEP_GRID (grid of a step launch, default 2048). */
 #define OCRGPU_F_NANNY 1u  /* detect double satisfy of an EDT pre-slot (hc-task.c:1243); +1 atomic per edge */
 #define OCRGPU_F_TIMING 2u /* bracket resolve's kernels with HIP events on the engine stream   */
+#define OCRGPU_F_NO_ASYNC 32u /* ocrgpu_resolve always runs level by level (one launch per level).  By default a resolve whose DAG is made of
+                              * ONCE / LATCH events, NOP / HASH bodies without scripts and dependences whose payload is known at registration, and
+                              * that starts from at most 65 536 ready EDTs, runs as ONE barrier-free kernel with the level carried as data (same
+                              * record).  Environment: OCRGPU_ASYNC=0 never, 2 whenever the DAG allows; OCRGPU_ASYNC_WAVES.        */
 #define OCRGPU_F_WIDE_DB 16u /* every ocrgpu_db_create datablock also carries an 8x8 tile of 64-bit integers (512 bytes, word w =
                               * ocrops_tile_init(value, w)) that OCRBODY_TILE bodies update in place -- the payload SURVEY.md s8d.3 names
                               * for the tiled Cholesky (regular-datablock.c:55-215: a datablock is its guid + a buffer the EDT writes).
@@ -107,6 +111,7 @@ typedef struct {
     uint64_t err[8];        /* [0] double slot satisfy [1] waiter on dead non-persistent event
                                [2] STICKY re-satisfied [3] satisfy/destroy of a dead event
                                [4] malformed op / unknown guid [5] queue overflow [6] level log overflow */
+    uint64_t async_runs;    /* resolves so far that ran as ONE barrier-free kernel (see OCRGPU_F_NO_ASYNC); such a run counts one launch */
 } ocrgpu_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

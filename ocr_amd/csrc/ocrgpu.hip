@@ -76,12 +76,12 @@ struct EvtRec { u32 row_begin, deg, state_kind; s32 val; };
 // counter the atomics hit, the record the firing lane reads, the ONCE output event (event index max_evt+e)
 // and up to 5 pre-slot payload words.  EDTs with depc > 5 keep their slot words in `slots[slot_ovf..]`.
 // {pending, level} is ONE aligned 8-byte word: the barrier-free resolve (k_async) counts a pre-slot down with a 64-bit returning
-// add that brings the level back with the count.  {val, out_state, body} is ONE aligned 16-byte granule: a body publishes its
-// value and BODY_VAL_DONE with one store, so a consumer that reads the granule in one load never pairs a flag with an old value.
+// add that brings the level back with the count.  {param0, val} is ONE aligned 16-byte unit: a consumer's body gets the producer's
+// tag and value in one load.  val is 0 until the body has run (k_async's consumers go by that, see there); BODY_VAL_DONE says so too.
 struct alignas(64) EdtLine {
     u32 pending, level;                   // level: 1 + the highest level among the EDTs that satisfied a pre-slot so far (k_async only)
-    u64 param0;                           // paramv[0]
-    u64 val; u32 out_state, body;         // the body's fold (== value of the output DB); state | kind<<8 of the ONCE output event
+    u32 out_state, body;                  // state | kind<<8 of the ONCE output event; body kind and flags
+    u64 param0, val;                      // paramv[0]; the body's fold (== value of the output DB): together the datablock {tag, value}
     u32 out_row, out_deg;                 // CSR row of the output event's waiters
     u32 depc;
     u32 slot[INLINE_SLOTS];               // depc <= 5: the pre-slot words; else slot[0] = base index into `slots`
@@ -127,7 +127,7 @@ struct alignas(128) State {
 struct alignas(128) Cnt { u32 v; u32 pad[31]; };
 struct alignas(128) Ctrl {
     // between runs ("absolute" view, used by the API kernels and by k_begin / k_end)
-    u32 level, r_end, q_begin, pad0, n_levels, b_begin, b_end, pad1[25];
+    u32 level, r_end, q_begin, async_block /* objects / dependences k_async does not take (see there) */, n_levels, b_begin, b_end, max_row /* longest waiter row (seal) */, pad1[24];
     u32 r_tail; u32 pad2[31];   // atomics (own cache lines)
     u32 q_tail; u32 pad3[31];
     u32 log_tail; u32 rdst_tail; u32 chan_count, chan_wait_used, chan_sat_used;
@@ -658,8 +658,8 @@ struct Seg { u32 row, end_off, payload; }; // end_off = inclusive prefix sum of 
 __device__ __forceinline__ ulonglong2 db_gather(const Dev &d, u32 p) {
     if (p == 0) return make_ulonglong2(0, ~0ULL);
     if (p - 1 < d.max_db) return d.db[p - 1];
-    const EdtLine *P = &d.edt[p - 1 - d.max_db];
-    return make_ulonglong2(P->val, d.hash_tag_base + P->param0);
+    const ulonglong2 pv = *reinterpret_cast<const ulonglong2 *>(&d.edt[p - 1 - d.max_db].param0);
+    return make_ulonglong2(pv.y, d.hash_tag_base + pv.x);
 }
 
 // queue a satisfy for another partition: per-destination send buffer, DB shipped by value
@@ -798,8 +798,7 @@ __device__ __forceinline__ u32 block_inclusive_scan(u32 v, u32 *wave_sums, u32 &
 }
 
 // the body proper: fold id + every depv[k] payload (8 pre-slots per round of loads; gb = the first round, already loaded)
-// value, output-event state and body word go out as ONE 16-byte store (`ostate` / `body`: what the line holds for them now)
-__device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, const u32 *sl, ulonglong2 (&gb)[8], u32 ostate, u32 body) {
+__device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, const u32 *sl, ulonglong2 (&gb)[8], u32 body) {
     u64 v = ocrops_hash_init(id);
     for (u32 k0 = 0; k0 < depc; k0 += 8) {
         if (k0) {
@@ -809,7 +808,8 @@ __device__ __forceinline__ void run_body(const Dev &d, u32 e, u64 id, u32 depc, 
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (k0 + k < depc) v = ocrops_hash_step(v, k0 + k, gb[k].x, gb[k].y + 1);
     }
-    *reinterpret_cast<uint4 *>(&d.edt[e].val) = make_uint4((u32)v, (u32)(v >> 32), ostate, body | BODY_VAL_DONE); // val == the output DB's value (a live DB only for HASH bodies)
+    d.edt[e].val = v; // == the output DB's value (a live DB only for HASH bodies)
+    d.edt[e].body = body | BODY_VAL_DONE;
 }
 
 // OCRBODY_TILE (8x8 int64 tiles updated in place by integer recurrences): the pre-slots that carry a datablock
@@ -886,7 +886,7 @@ __device__ __forceinline__ void deferred_body(const Dev &d, u32 e, bool &tile, u
     if (TILES && OCRBODY_KIND(L.body) == OCRBODY_TILE) { tile = true; tile_operands(pw, L.depc, tt); return; }
 #pragma unroll
     for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
-    run_body(d, e, L.param0, L.depc, sl, gb, L.out_state, L.body);
+    run_body(d, e, L.param0, L.depc, sl, gb, L.body);
 }
 template <bool TILES>
 __device__ void deferred_bodies(const Dev &d, u32 b_begin, u32 b_end, u32 h, u32 nh) {
@@ -1030,10 +1030,10 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (i < S.r_end) e = d.fired[i];
             const bool mine = e != INVALID;
             bool epi = false;
-            u32 body = 0, depc = 0, ostate = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr; ulonglong2 gb[8]; u32 tt[3] = {0, 0, 0};
+            u32 body = 0, depc = 0, pw[8]; u64 id = 0; const u32 *sl = nullptr; ulonglong2 gb[8]; u32 tt[3] = {0, 0, 0};
             if (mine) {
                 const EdtLine L = d.edt[e]; // the one 64-B read that carries everything this EDT needs to fire
-                body = L.body; depc = L.depc; id = L.param0; ostate = L.out_state;
+                body = L.body; depc = L.depc; id = L.param0;
                 const u32 x = d.max_evt + e;
                 if (depc <= INLINE_SLOTS) {
 #pragma unroll
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                 // With other partitions around, a satisfy may carry this EDT's output DB away by value in this very
                 // launch, so the body runs first; on a single partition it runs after the fan-out (off the critical path).
                 const bool host_body = kind == OCRBODY_HOST; // taskExecute happens on the host (ocrgpu_pop_ready)
-                if (body_first && !host_body && kind != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, ostate, body); // (tile datablocks: one partition only)
+                if (body_first && !host_body && kind != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, body); // (tile datablocks: one partition only)
                 if (body & BODY_F_SCRIPT) { // the body's own ocrEventSatisfySlot / ocrEventDestroy calls
                     u32 sb = d.edt_script_begin[e], sn = d.edt_script_len[e];
                     for (u32 k = 0; k < sn; ++k) {
@@ -1090,7 +1090,6 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                     bool ok = true;
                     if (NANNY) ok = evt_satisfy_simple(d, x, OCREVT_ONCE, ret);
                     else d.edt[e].out_state = ST_DESTROYED | (OCREVT_ONCE << 8); // only its own EDT satisfies it
-                    ostate = ST_DESTROYED | (OCREVT_ONCE << 8);
                     if (ok && !split_big_row(d, S, x, L.out_deg, ret)) { deg = L.out_deg; sg.row = L.out_row; sg.payload = ret; }
                 }
             }
@@ -1104,7 +1103,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             STAMP(2);
             if (total) fan_out<NANNY, LOCKABLE, TILES>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             STAMP(3);
-            if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST && OCRBODY_KIND(body) != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, ostate, body);
+            if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST && OCRBODY_KIND(body) != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, body);
             if (TILES) tile_bodies_wave(d, mine && !defer && OCRBODY_KIND(body) == OCRBODY_TILE, e, tt);
         }
     } else {
@@ -1240,6 +1239,462 @@ __device__ __forceinline__ void end_of_run(const Dev &d, u32 K) {
 __global__ void k_end(Dev d, u32 K) { end_of_run(d, K); }
 
 // ------------------------------------------------------------------------------------------------
+// the barrier-free resolve: one resident kernel, no level barrier, the level carried as data
+// ------------------------------------------------------------------------------------------------
+// A chain of narrow levels (config 2: 1000 levels of 10 000 EDTs) costs a level-synchronous engine one launch and one cold burst of
+// dependent memory trips per level, whatever its stages do.  Here an EDT fires as soon as it is ready, in the launch
+// that made it ready: waves take ready EDTs from ticket queues, fan their output events out (commonSatisfyWaiters, hc-event.c:369
+// -> satisfyTaskHc, hc-task.c:1216-1266, exactly as k_step's FIRE pass does), and hand the EDTs they make ready to the queues --
+// the reference's own order of work (depth first, no levels at all, hc-event.c:369-433), on 1024 waves.  The parity contract's
+// per-level fired SETS stay exact because the level is data: level(EDT) = 1 + max level(its satisfiers), kept with an atomicMax
+// on EdtLine.level issued in FRONT of the returning add on EdtLine.pending of the same 8-byte word -- the add that takes pending to
+// zero brings the final level back -- which is what the replay harness's Lamport clock does on the reference
+// (oracle/ocr_replay.c:167-181).  The fired log is rebuilt grouped by level when the kernel has ended (k_async_hist / _scan /
+// _scatter), so everything behind ocrgpu_resolve reads what it always read.
+// What may run this way (anything else takes the level-synchronous path): one partition, no NANNY / Lockable / tile engine; only
+// ONCE and LATCH events; NOP / HASH bodies without scripts; every registered dependence either an EDT pre-slot whose payload word
+// was written at registration (RF_PREFILLED) or a LATCH DECR slot -- objects whose firing does not depend on the order of their
+// satisfies (a latch that only counts down fires on its last DECR whoever brings it).  Ctrl.async_block counts what falls outside.
+// Values: a body publishes its value with one 8-byte sc1 store; a consumer's body gathers its producers' {param0, val} with
+// 16-byte sc1 loads and looks again in the rare case a value is still 0 (the body runs behind the hand-over of the EDTs its
+// wave made ready, so nothing on the dependence path waits for a value).
+#ifndef OCRGPU_AEXP
+#define OCRGPU_AEXP 0
+#endif
+#define ANSH 8u             // queue shards (a wave takes tickets from shard wave % 8 and hands over to shard (wave + iteration) % 8)
+#define AROW 8u             // waiters of an EDT's output event kept beside the line, indexed by EDT (Dev-free: ADev.irow)
+#define A_EVT 0x80000000u   // queue entry id: a fired event (index + 1) instead of a ready EDT (index + 1)
+#define A_OUT 512u          // ready entries a wave collects before it hands them over
+#define ALAT_BIAS 0x40000000u
+#define AMAX_ROW 1024u      // rows longer than this: level-synchronous path (its big-row pieces spread over the grid)
+#define AMAX_SEEDS 65536u   // more ready EDTs than this at the start: a wide DAG, atomic-rate bound, better served level by level
+struct alignas(128) AShard { u32 tail; u32 p0[31]; u32 head; u32 p1[31]; u64 acct; u32 p2[30]; }; // acct = entries consumed << 32 | busy waves
+struct ACtl { AShard sh[ANSH]; u32 old_tail[ANSH]; u32 L0, seed_begin, seed_end, max_level, n_lv_prev, total_out, pad[2]; };
+struct ADev { ACtl *c; u64 *q; u64 *irow; u64 *alat; u32 *hist; u32 cap, refill, n_evt, pad; };
+
+__device__ __forceinline__ u32 a_ld(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 a_ld(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void a_st16(void *p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+// Eight 16-byte sc1 loads in flight, one wait (which also covers what the wave issued before the block).  Load k is made by the
+// lanes of mask m[k] only (EXEC is narrowed around it): a wave holds about 14 EDTs with 4 pre-slots each, and the idle lanes and
+// unused pre-slots would otherwise put seven times as many requests on the fabric as the real ones.  g[k] of a lane outside m[k] is
+// not written.
+__device__ __forceinline__ void a_gather8(const void *const (&p)[8], const u64 (&m)[8], u32x4 (&g)[8]) {
+    u64 sav;
+    asm volatile("s_mov_b64 %8, exec\n\t"
+                 "s_mov_b64 exec, %17\n\tglobal_load_dwordx4 %0, %9, off sc1\n\t"
+                 "s_mov_b64 exec, %18\n\tglobal_load_dwordx4 %1, %10, off sc1\n\t"
+                 "s_mov_b64 exec, %19\n\tglobal_load_dwordx4 %2, %11, off sc1\n\t"
+                 "s_mov_b64 exec, %20\n\tglobal_load_dwordx4 %3, %12, off sc1\n\t"
+                 "s_mov_b64 exec, %21\n\tglobal_load_dwordx4 %4, %13, off sc1\n\t"
+                 "s_mov_b64 exec, %22\n\tglobal_load_dwordx4 %5, %14, off sc1\n\t"
+                 "s_mov_b64 exec, %23\n\tglobal_load_dwordx4 %6, %15, off sc1\n\t"
+                 "s_mov_b64 exec, %24\n\tglobal_load_dwordx4 %7, %16, off sc1\n\t"
+                 "s_mov_b64 exec, %8\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]), "=&s"(sav)
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),
+                   "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]) : "memory");
+}
+// Termination: no wave busy and every reserved entry consumed, seen twice in a row.  tail and consumed only grow, and busy only
+// rises in the same atomic as consumed: two equal snapshots are one consistent view.
+__device__ bool a_quiescent(const ADev &a) {
+    const u32 lane = lane_id();
+    u64 x = 0, y = 0; u32 tx = 0, ty = 0;
+    if (lane < ANSH) { x = a_ld(&a.c->sh[lane].acct); tx = a_ld(&a.c->sh[lane].tail); }
+    if (lane < ANSH) { y = a_ld(&a.c->sh[lane].acct); ty = a_ld(&a.c->sh[lane].tail); }
+    if (__ballot(x != y || tx != ty)) return false;
+    u64 cons = x >> 32, busy = x & 0xFFFFFFFFull, tl = tx;
+    for (int o = 1; o < (int)ANSH; o <<= 1) { cons += __shfl_xor(cons, o); busy += __shfl_xor(busy, o); tl += __shfl_xor(tl, o); }
+    cons = __shfl(cons, 0); busy = __shfl(busy, 0); tl = __shfl(tl, 0);
+    return (busy & 0xFFFFFFFFull) == 0 && cons == tl;
+}
+// one dependence edge per lane: the atomics go out here, what they returned is looked at in a_collect (several edges in flight)
+struct AEdge { u64 o; u32 dst, fl, slv; bool act; };
+__device__ __forceinline__ void a_issue(const Dev &d, bool act, u64 w, u32 slv, AEdge &r) {
+    const u32 hi = (u32)(w >> 32), slot = hi & 0x0FFFFFFFu;
+    r.act = act; r.dst = (u32)w; r.fl = hi >> 28; r.slv = slv; r.o = 0;
+    if (act && (r.fl & RF_DST_EDT)) { // satisfyTaskHc: the level first, then ONE 64-bit returning add on {pending, level} (same word: it cannot overtake the max)
+        EdtLine *D = &d.edt[r.dst];
+        atomicMax(&D->level, slv + 1u);
+        r.o = atomicAdd((unsigned long long *)D, (r.fl & RF_INLINE) ? (unsigned long long)(PEND_INL_BIT(slot) - 1u) : ~0ull);
+    }
+}
+// EDTs made ready go to lds_id / lds_lv; LATCH destinations are only noted (lds_lat: {latch, level}) -- every leaf of a finish scope
+// hits the same counter word, and a wave that waited for that word here would hold back the EDTs it has just made ready
+#define A_LAT 128u
+__device__ __forceinline__ void a_collect(const AEdge &r, u32 *lds_id, u32 *lds_lv, u32 *lds_lat, u32 &nready, u32 &nlat, u64 &n_edt_sat, u64 &n_evt_sat) {
+    const bool to_edt = r.act && (r.fl & RF_DST_EDT), to_lat = r.act && !to_edt;
+    const bool ready = to_edt && ((u32)r.o & ((r.fl & RF_INLINE) ? PEND_INL_CNT : PEND_MASK)) == 1u;
+    const u64 em = __ballot(to_edt), lm = __ballot(to_lat), rm = __ballot(ready);
+    n_edt_sat += __popcll(em); n_evt_sat += __popcll(lm);
+    if (ready) {
+        const u32 pos = nready + rank_in(rm);
+        u32 lv = (u32)(r.o >> 32); if (lv < r.slv + 1u) lv = r.slv + 1u;
+        if (pos < A_OUT) { lds_id[pos] = r.dst + 1u; lds_lv[pos] = lv; }
+    }
+    nready += (u32)__popcll(rm);
+    if (to_lat) { const u32 pos = nlat + rank_in(lm); if (pos < A_LAT) { lds_lat[2 * pos] = r.dst; lds_lat[2 * pos + 1] = r.slv; } }
+    nlat += (u32)__popcll(lm);
+}
+// satisfyEventHcLatch (hc-event.c:812-868), DECR only, for the noted edges: the lanes of one latch take ONE returning add with their
+// count, behind an atomicMax with their highest level; the add that leaves zero fires the latch (once; it is destroyed, :836,885)
+__device__ void a_latches(const Dev &d, const ADev &a, const u32 *lds_lat, u32 nlat, u32 *lds_id, u32 *lds_lv, u32 &nready) {
+    const u32 lane = lane_id();
+    for (u32 base = 0; base < nlat; base += 64) {
+        const bool act = base + lane < nlat;
+        const u32 x = act ? lds_lat[2 * (base + lane)] : 0u, slv = act ? lds_lat[2 * (base + lane) + 1] : 0u;
+        bool lead = false; u32 gcnt = 0, glvl = 0; u64 o = 0;
+        u64 todo = __ballot(act);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const u32 x0 = __shfl(x, leader);
+            const u64 grp = __ballot(act && x == x0) & todo;
+            u32 m = (act && x == x0) ? slv : 0u;
+            for (int s = 1; s < 64; s <<= 1) { const u32 n = __shfl_xor(m, s); m = n > m ? n : m; }
+            if ((int)lane == leader) {
+                lead = true; gcnt = (u32)__popcll(grp); glvl = m;
+                atomicMax(reinterpret_cast<u32 *>(&a.alat[x0]) + 1, m);
+                o = atomicAdd((unsigned long long *)&a.alat[x0], 0ull - (unsigned long long)gcnt);
+            }
+            todo &= ~grp;
+        }
+        bool ready = false; u32 lv = 0;
+        if (lead && (u32)o - gcnt == ALAT_BIAS) {
+            const u32 was = atomicExch(evt_state(d, x), ST_DESTROYED | (OCREVT_LATCH << 8));
+            if ((was & 0xFF) != ST_LIVE) atomicAdd(&d.ctrl->err[ERR_DEAD_EVENT], 1u);
+            else if (d.evt[x].deg) { ready = true; lv = (u32)(o >> 32); if (lv < glvl) lv = glvl; }
+        }
+        const u64 rm = __ballot(ready);
+        if (ready) { const u32 pos = nready + rank_in(rm); if (pos < A_OUT) { lds_id[pos] = A_EVT | (x + 1u); lds_lv[pos] = lv; } }
+        nready += (u32)__popcll(rm);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_async(Dev d, ADev a) {
+    __shared__ u64 lds_w[AROW * 32];
+    __shared__ u32 lds_l[AROW * 32];
+    __shared__ u32 lds_id[A_OUT], lds_lv[A_OUT];
+    __shared__ u32 lds_lat[2 * A_LAT];
+    const u32 lane = threadIdx.x, wid = blockIdx.x, sh = wid & (ANSH - 1u);
+    ACtl *c = a.c;
+    AShard *S = &c->sh[sh];
+    const u64 *Q = a.q + (size_t)sh * a.cap;
+    u32 item = INVALID, lvl = 0, ticket = INVALID, spins = 0, iter = 0, max_lv = 0;
+    bool busy = false; // (wave-uniform) this wave is counted in its shard's busy total
+    u64 n_edt_sat = 0, n_evt_sat = 0, n_fired = 0;
+#ifdef OCRGPU_ASTAMPS
+    u64 s_iter = 0, s_titer = 0, s_tbody = 0, s_idle = 0, s_items = 0, s_thand = 0, s_tload = 0, s_tfan = 0, s_lat = 0, s_tlat = 0, s_tgat = 0;
+#define ASTAMP(x) x
+#else
+#define ASTAMP(x)
+#endif
+    // hand the collected entries to a queue: one returning add reserves, the entries go out as 8-byte sc1 stores
+    auto hand_over = [&](u32 &nready) {
+        if (nready > A_OUT) nready = A_OUT; // (cannot happen: the callers flush in time)
+        if (!nready) return;
+        const u32 tsh = (sh + iter) & (ANSH - 1u);
+        u32 qb = 0;
+        if (lane == 0) qb = atomicAdd(&c->sh[tsh].tail, nready);
+        qb = __shfl(qb, 0);
+        u64 *QT = a.q + (size_t)tsh * a.cap;
+        for (u32 i = lane; i < nready; i += 64) {
+            if (qb + i < a.cap) __hip_atomic_store(&QT[qb + i], ((u64)lds_lv[i] << 32) | (u64)lds_id[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+        }
+        nready = 0;
+    };
+    for (;;) {
+        bool got = false;
+        if (ticket != INVALID) { const u64 v = a_ld(&Q[ticket]); if ((u32)v) { item = (u32)v; lvl = (u32)(v >> 32); ticket = INVALID; got = true; } }
+        const u64 gm = __ballot(got), hm = __ballot(item != INVALID);
+        if (gm) { // entries consumed (+ idle -> busy) in ONE atomic: "consumed" never shows without the "busy" that goes with it
+            if (lane == 0) atomicAdd((unsigned long long *)&S->acct, ((unsigned long long)__popcll(gm) << 32) + (busy ? 0ull : 1ull));
+            busy = true;
+        }
+        if (!hm) {
+            if (busy) { if (lane == 0) atomicAdd((unsigned long long *)&S->acct, ~0ull); busy = false; } // (behind the hand-over's returned add)
+            const u64 fm = __ballot(lane < a.refill && ticket == INVALID);
+            if ((u32)__popcll(fm) * 2 >= a.refill) { // at least half of the ticket lanes are free: take tickets for them
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(&S->head, (u32)__popcll(fm));
+                base = __shfl(base, 0);
+                if (lane < a.refill && ticket == INVALID && base + rank_in(fm) < a.cap) ticket = base + rank_in(fm);
+                if (base >= a.cap) { if (a_quiescent(a)) break; __builtin_amdgcn_s_sleep(64); }
+                continue;
+            }
+            // waiting: every wave polls its OWN ticket words (polling a shared word from hundreds of waves slows every request that
+            // shares its channel: measured); the shared totals are looked at rarely
+            ++spins; ASTAMP(++s_idle);
+            if ((spins & 31u) == 0 && a_quiescent(a)) break;
+            if (spins < 8) __builtin_amdgcn_s_sleep(2); else if (spins < 32) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
+            continue;
+        }
+        spins = 0; ++iter;
+        ASTAMP(const u64 t_in = __builtin_amdgcn_s_memrealtime(); ++s_iter; s_items += __popcll(hm));
+        const bool has = item != INVALID, is_evt = has && (item & A_EVT) != 0, is_edt = has && !is_evt;
+        const u32 idx = has ? (item & ~A_EVT) - 1u : 0u;
+        // ---- one trip: the EDT's line and its inline waiter row (both addressed by the EDT's index alone) ----
+        u64 rw[AROW]; u32 row = 0, deg = 0, body = 0, depc = 0, ostate = 0, sl[INLINE_SLOTS]; u64 param0 = 0;
+#pragma unroll
+        for (int k = 0; k < (int)AROW; ++k) rw[k] = 0;
+#pragma unroll
+        for (int k = 0; k < (int)INLINE_SLOTS; ++k) sl[k] = 0;
+        if (is_edt) {
+            const EdtLine *L = &d.edt[idx];
+            const ulonglong2 *R = reinterpret_cast<const ulonglong2 *>(a.irow + (size_t)idx * AROW);
+#pragma unroll
+            for (int k = 0; k < (int)AROW / 2; ++k) { const ulonglong2 x = R[k]; rw[2 * k] = x.x; rw[2 * k + 1] = x.y; }
+            body = L->body; depc = L->depc; param0 = L->param0; ostate = L->out_state; row = L->out_row;
+            deg = (body & OCRBODY_F_OUTEVT) ? L->out_deg : 0u;
+#pragma unroll
+            for (int k = 0; k < (int)INLINE_SLOTS; ++k) sl[k] = L->slot[k];
+            if (lvl > max_lv) max_lv = lvl;
+        } else if (is_evt) { const EvtRec r = d.evt[idx]; row = r.row_begin; deg = r.deg; }
+        n_fired += __popcll(__ballot(is_edt)); n_evt_sat += __popcll(__ballot(is_edt && (body & OCRBODY_F_OUTEVT))); // the epilogue's satisfy of the output event
+        const u32 cnt = is_edt ? (deg < AROW ? deg : AROW) : 0u, rem = deg - cnt;
+        u32 incl = cnt;
+        for (u32 o = 1; o < a.refill; o <<= 1) { const u32 nb = __shfl_up(incl, o); if (lane >= o) incl += nb; } // (items sit in the ticket lanes)
+        const u32 total = __shfl(incl, a.refill - 1u), excl = incl - cnt;
+#pragma unroll
+        for (int k = 0; k < (int)AROW; ++k) if ((u32)k < cnt) { lds_w[excl + k] = rw[k]; lds_l[excl + k] = lvl; }
+        __syncthreads();
+        ASTAMP(const u64 t_ld = __builtin_amdgcn_s_memrealtime(); s_tload += t_ld - t_in);
+        // overflow pre-slot words of the body's first round (EDTs with more than 5 pre-slots): asked for beside the atomics below
+        u32 ow[8];
+        {
+            const u32 *ov = d.slots + sl[0];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ow[k] = (is_edt && depc > INLINE_SLOTS && (u32)k < depc) ? ov[k] : 0u;
+        }
+        u32 nready = 0, nlat = 0;
+        for (u32 base = 0; base < total; base += 128) {
+            AEdge e0, e1;
+            { const u32 t = base + lane; const bool act = t < total; a_issue(d, act, act ? lds_w[t] : 0ull, act ? lds_l[t] : 0u, e0); }
+            { const u32 t = base + 64 + lane; const bool act = t < total; a_issue(d, act, act ? lds_w[t] : 0ull, act ? lds_l[t] : 0u, e1); }
+            if (nlat + 128 > A_LAT) { __syncthreads(); a_latches(d, a, lds_lat, nlat, lds_id, lds_lv, nready); nlat = 0; __syncthreads(); }
+            a_collect(e0, lds_id, lds_lv, lds_lat, nready, nlat, n_edt_sat, n_evt_sat);
+            a_collect(e1, lds_id, lds_lv, lds_lat, nready, nlat, n_edt_sat, n_evt_sat);
+        }
+        // rows longer than the inline part, and the rows of fired events: edge-balanced over the wave straight from waiters[]
+        u32 rincl = rem, rtotal = 0;
+        if (__ballot(rem != 0)) {
+            for (u32 o = 1; o < a.refill; o <<= 1) { const u32 nb = __shfl_up(rincl, o); if (lane >= o) rincl += nb; }
+            rtotal = __shfl(rincl, a.refill - 1u);
+        }
+        const u32 rexcl = rincl - rem;
+        for (u32 base = 0; base < rtotal; base += 64) {
+            const u32 t = base + lane; const bool act = t < rtotal;
+            u32 lo = 0, hi = a.refill - 1u;
+            while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (__shfl(rincl, mid) > t) hi = mid; else lo = mid + 1; }
+            const u32 start = __shfl(rexcl, lo), r0 = __shfl(row + cnt, lo), slv = __shfl(lvl, lo);
+            AEdge e0;
+            a_issue(d, act, act ? d.waiters[r0 + (t - start)] : 0ull, slv, e0);
+            if (nready + 64 > A_OUT) { __syncthreads(); hand_over(nready); __syncthreads(); }
+            if (nlat + 64 > A_LAT) { __syncthreads(); a_latches(d, a, lds_lat, nlat, lds_id, lds_lv, nready); nlat = 0; __syncthreads(); }
+            a_collect(e0, lds_id, lds_lv, lds_lat, nready, nlat, n_edt_sat, n_evt_sat);
+        }
+        __syncthreads();
+        ASTAMP(const u64 t_fan = __builtin_amdgcn_s_memrealtime(); s_tfan += t_fan - t_ld);
+        hand_over(nready);
+        ASTAMP(const u64 t_ho = __builtin_amdgcn_s_memrealtime(); s_thand += t_ho - t_fan; s_titer += t_ho - t_in);
+        // ---- behind the hand-over: the latch edges, then the body (taskExecute's user function; the epilogue's output-event satisfy
+        // was the fan-out above) ----
+        if (nlat) { a_latches(d, a, lds_lat, nlat, lds_id, lds_lv, nready); __syncthreads(); hand_over(nready); }
+        ASTAMP(const u64 t_la = __builtin_amdgcn_s_memrealtime(); s_tlat += t_la - t_ho);
+        if (__ballot(is_edt)) {
+            u64 v = ocrops_hash_init(param0);
+            const u32 *ov = d.slots + sl[0];
+            for (u32 k0 = 0; __ballot(is_edt && k0 < depc); k0 += 8) {
+                u32 pw[8]; const void *ga[8]; u32x4 g[8]; u64 gm8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    u32 p = 0;
+                    if (is_edt && k0 + k < depc) {
+                        if (depc <= INLINE_SLOTS) p = k < (int)INLINE_SLOTS ? sl[k < (int)INLINE_SLOTS ? k : 0] : 0u;
+                        else p = k0 ? ov[k0 + k] : ow[k];
+                    }
+                    p &= 0x7FFFFFFFu; pw[k] = p;
+                    if (p == 0) ga[k] = &d.edt[0].val;                                   // NULL_GUID: nothing to read (the lane sits this load out)
+                    else if (p - 1 < d.max_db) ga[k] = &d.db[p - 1];                    // an explicit datablock {value, tag}: not written during a resolve
+                    else ga[k] = &d.edt[p - 1 - d.max_db].param0;                          // a producer's {param0, val}
+                    gm8[k] = __ballot(p != 0);
+                }
+                for (u32 tries = 0;; ++tries) { // (rare) a producer's value is not there yet: its body runs behind its hand-over, ours may have overtaken it
+                    a_gather8(ga, gm8, g);
+                    // A producer's value is there when it is not 0: val is 0 from creation until the body's one 8-byte store.  (A fold
+                    // that IS 0 -- one in 2^64 -- makes its consumers look until they give up, and then they use the 0 they read: right.)
+                    bool ok = true;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (pw[k] && pw[k] - 1 >= d.max_db && (g[k].z | g[k].w) == 0u) ok = false;
+                    if (!__ballot(!ok)) break;
+                    ASTAMP(++s_lat);
+                    if (tries > (1u << 18)) break; // (values of EDTs that may never run are kept off this path: k_add_dep / k_satisfy)
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                ASTAMP(s_tgat += __builtin_amdgcn_s_memrealtime() - t_la);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (is_edt && k0 + k < depc) {
+                    u64 val = 0, tag = ~0ULL;
+                    if (pw[k]) { // an explicit datablock is {value, tag}, a producer's line {param0, val}
+                        const u64 lo = ((u64)g[k].y << 32) | g[k].x, hi = ((u64)g[k].w << 32) | g[k].z;
+                        if (pw[k] - 1 < d.max_db) { val = lo; tag = hi; } else { val = hi; tag = d.hash_tag_base + lo; }
+                    }
+                    v = ocrops_hash_step(v, k0 + k, val, tag + 1);
+                }
+            }
+            if (is_edt) {
+                __hip_atomic_store(&d.edt[idx].val, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the value consumers wait for: one 8-byte sc1 store
+                // satisfyEventHcOnce: the output event has fired and is destroyed; the body has run (read after this launch only)
+                *reinterpret_cast<uint2 *>(&d.edt[idx].out_state) = make_uint2((body & OCRBODY_F_OUTEVT) ? (u32)(ST_DESTROYED | (OCREVT_ONCE << 8)) : ostate, body | BODY_VAL_DONE);
+            }
+        }
+        item = INVALID;
+        __syncthreads();
+        ASTAMP(s_tbody += __builtin_amdgcn_s_memrealtime() - t_ho);
+    }
+#ifdef OCRGPU_ASTAMPS
+    if (lane == 0) { unsigned long long *g = (unsigned long long *)d.dbg + 32; atomicAdd(g, s_iter); atomicAdd(g + 1, s_titer); atomicAdd(g + 2, s_tbody); atomicAdd(g + 3, s_idle);
+                     atomicAdd(g + 4, s_items); atomicAdd(g + 5, s_thand); atomicAdd(g + 6, s_tload); atomicAdd(g + 7, s_tfan); atomicAdd(g + 8, s_lat); atomicAdd(g + 9, s_tlat); atomicAdd(g + 10, s_tgat); }
+#endif
+    if (lane == 0) {
+        if (n_edt_sat | n_evt_sat | n_fired) {
+            unsigned long long *bs = (unsigned long long *)(d.blk_stats + 4 * (blockIdx.x % MAX_GRID));
+            atomicAdd(bs, (unsigned long long)n_edt_sat); atomicAdd(bs + 1, (unsigned long long)n_evt_sat); atomicAdd(bs + 2, (unsigned long long)n_fired);
+        }
+    }
+    u32 m = max_lv;
+    for (int o = 1; o < 64; o <<= 1) { const u32 n = __shfl_xor(m, o); m = n > m ? n : m; }
+    if (lane == 0 && m) atomicMax(&c->max_level, m);
+}
+
+// before a run: clear what the last run left in the queues and in the level histogram
+__global__ void k_async_reset(ADev a) {
+    const ACtl *c = a.c;
+    const u64 gs = (u64)gridDim.x * blockDim.x, t0 = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    for (u32 s = 0; s < ANSH; ++s) { const u32 n = c->old_tail[s] < a.cap ? c->old_tail[s] : a.cap; for (u64 i = t0; i < n; i += gs) a.q[(size_t)s * a.cap + i] = 0; }
+    for (u64 i = t0; i < (u64)c->n_lv_prev + 2; i += gs) a.hist[i] = 0;
+}
+__global__ void k_async_init(Dev d, ADev a) { // one wave
+    ACtl *c = a.c;
+    const u32 t = threadIdx.x;
+    if (t < ANSH) { c->sh[t].tail = 0; c->sh[t].head = 0; c->sh[t].acct = 0; c->old_tail[t] = 0; }
+    if (t == 0) { c->L0 = d.ctrl->level + 1u; c->seed_begin = d.ctrl->r_end; c->seed_end = d.ctrl->r_tail; c->max_level = d.ctrl->level + 1u; c->n_lv_prev = 0; c->total_out = 0; }
+}
+// the seeds: what the main program's satisfies made ready (the sparse ready log [r_end, r_tail)) enters the queues at level L0;
+// every LIVE latch gets its biased counter word {count + bias, level 0}
+__global__ void k_async_seed(Dev d, ADev a) {
+    ACtl *c = a.c;
+    const u64 gs = (u64)gridDim.x * blockDim.x, t0 = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    for (u64 x = t0; x < a.n_evt; x += gs) if (((d.evt[x].state_kind >> 8) & 0xFF) == OCREVT_LATCH) a.alat[x] = (u64)((u32)d.evt[x].val + ALAT_BIAS);
+    const u32 b = c->seed_begin, n = c->seed_end - b;
+    for (u64 i0 = (t0 & ~63ull); i0 < n; i0 += gs) { // (whole waves stay together: the append below is wave-wide)
+        const u64 i = i0 + (t0 & 63u);
+        const u32 e = i < n ? d.fired[b + i] : INVALID;
+        const u32 s = (u32)((i0 / 64) % ANSH);
+        const u64 m = __ballot(e != INVALID);
+        if (!m) continue;
+        u32 base = 0; const int leader = __ffsll((long long)m) - 1;
+        if ((int)lane_id() == leader) base = atomicAdd(&c->sh[s].tail, (u32)__popcll(m));
+        base = __shfl(base, leader);
+        if (e != INVALID) a.q[(size_t)s * a.cap + base + rank_in(m)] = ((u64)c->L0 << 32) | (u64)(e + 1u);
+    }
+}
+// after the run: the fired log grouped by level, from the queue entries (every EDT that fired is exactly one entry)
+__global__ void k_async_hist(Dev d, ADev a) {
+    const ACtl *c = a.c;
+    const u64 gs = (u64)gridDim.x * blockDim.x, t0 = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    for (u32 s = 0; s < ANSH; ++s) {
+        const u32 n = c->sh[s].tail < a.cap ? c->sh[s].tail : a.cap;
+        for (u64 i0 = (t0 & ~63ull); i0 < n; i0 += gs) {
+            const u64 i = i0 + (t0 & 63u);
+            const u64 v = i < n ? a.q[(size_t)s * a.cap + i] : 0ull;
+            const u32 id = (u32)v, lv = (u32)(v >> 32);
+            bool mine = id != 0 && !(id & A_EVT) && lv > c->L0;
+            if (mine && lv >= d.max_levels) { atomicAdd(&d.ctrl->err[ERR_LEVEL_OVERFLOW], 1u); mine = false; }
+            u64 todo = __ballot(mine);
+            while (todo) { // one atomic per distinct level per wave
+                const int leader = __ffsll((long long)todo) - 1;
+                const u32 l0 = __shfl(lv, leader);
+                const u64 grp = __ballot(mine && lv == l0) & todo;
+                if ((int)lane_id() == leader) atomicAdd(&a.hist[l0 - c->L0 - 1u], (u32)__popcll(grp));
+                todo &= ~grp;
+            }
+        }
+    }
+}
+// hist[k] (EDTs of level L0 + 1 + k) -> start offsets in the fired log behind the seeds; level_start[] for every level of the run
+__global__ __launch_bounds__(1024) void k_async_scan(Dev d, ADev a) {
+    __shared__ u32 ws[16]; __shared__ u32 carry_s;
+    ACtl *c = a.c;
+    const u32 L0 = c->L0;
+    u32 top = c->max_level; if (top >= d.max_levels) top = d.max_levels - 1;
+    const u32 n_lv = top - L0; // levels above the seeds
+    if (threadIdx.x == 0) { carry_s = c->seed_end; if (L0 < d.max_levels) { d.level_start[L0] = c->seed_begin; d.level_start[L0 + 1] = c->seed_end; } }
+    __syncthreads();
+    for (u32 base = 0; base < n_lv; base += 1024) {
+        const u32 k = base + threadIdx.x;
+        const u32 hv = k < n_lv ? a.hist[k] : 0u;
+        u32 v = hv;
+        const u32 lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int o = 1; o < 64; o <<= 1) { const u32 nb = __shfl_up(v, o); if (lane >= (u32)o) v += nb; }
+        if (lane == 63) ws[w] = v;
+        __syncthreads();
+        u32 add = carry_s;
+        for (u32 j = 0; j < w; ++j) add += ws[j];
+        const u32 excl = add + v - hv;
+        if (k < n_lv) { a.hist[k] = excl; d.level_start[L0 + 2 + k] = excl + hv; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = excl + hv;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { c->total_out = carry_s; c->n_lv_prev = n_lv; }
+}
+__global__ void k_async_scatter(Dev d, ADev a) {
+    const ACtl *c = a.c;
+    const u64 gs = (u64)gridDim.x * blockDim.x, t0 = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    for (u32 s = 0; s < ANSH; ++s) {
+        const u32 n = c->sh[s].tail < a.cap ? c->sh[s].tail : a.cap;
+        for (u64 i0 = (t0 & ~63ull); i0 < n; i0 += gs) {
+            const u64 i = i0 + (t0 & 63u);
+            const u64 v = i < n ? a.q[(size_t)s * a.cap + i] : 0ull;
+            const u32 id = (u32)v, lv = (u32)(v >> 32);
+            const bool mine = id != 0 && !(id & A_EVT) && lv > c->L0 && lv < d.max_levels;
+            u32 pos = 0;
+            u64 todo = __ballot(mine);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const u32 l0 = __shfl(lv, leader);
+                const u64 grp = __ballot(mine && lv == l0) & todo;
+                u32 base = 0;
+                if ((int)lane_id() == leader) base = atomicAdd(&a.hist[l0 - c->L0 - 1u], (u32)__popcll(grp));
+                base = __shfl(base, leader);
+                if (mine && lv == l0) pos = base + rank_in(grp);
+                todo &= ~grp;
+            }
+            if (mine) { if (pos < d.fired_cap) d.fired[pos] = id - 1u; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); }
+        }
+    }
+}
+// fold the run back into the between-runs view (what k_end does for a level-synchronous run); latch counters go back to their records
+__global__ void k_async_end(Dev d, ADev a, u32 K) {
+    ACtl *c = a.c;
+    const u64 gs = (u64)gridDim.x * blockDim.x, t0 = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    for (u64 x = t0; x < a.n_evt; x += gs) if (((d.evt[x].state_kind >> 8) & 0xFF) == OCREVT_LATCH) d.evt[x].val = (s32)((u32)a.alat[x] - ALAT_BIAS);
+    if (t0 == 0) {
+        Ctrl *k = d.ctrl;
+        u32 top = c->max_level; if (top >= d.max_levels) top = d.max_levels - 1;
+        u32 tot = c->total_out; if (tot > d.fired_cap) tot = d.fired_cap;
+        k->level = top; k->n_levels = top + 1u; k->r_end = tot; k->r_tail = tot; k->q_begin = 0; k->q_tail = 0; k->b_begin = k->b_end = 0;
+        for (u32 s = 0; s < ANSH; ++s) c->old_tail[s] = c->sh[s].tail;
+        State P; memset(&P, 0, sizeof P); // what a level-synchronous run's last launch would have left (ocrgpu_step_info, the host's polls)
+        P.mode = MODE_FIRE; P.level = top; P.n_levels = top + 1u; P.done = 1; P.allow_fire = 0xFFFFFFFFu;
+        P.r_begin = top < d.max_levels ? d.level_start[top] : tot; P.r_end = tot; P.r_total = tot;
+        k->state[K & 1] = P;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // construction kernels
 // ------------------------------------------------------------------------------------------------
 // `gin` != nullptr: the caller chose the guids (handed out earlier by ocrgpu_guid_reserve -- the reference's
@@ -1259,6 +1714,7 @@ __global__ void k_event_create(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n,
     if (i >= n) return;
     u32 k = kind[i], x = take_index(rc.free_evt, n_free, n_take, first_idx, i);
     rc.evt_guids[x] = 0;
+    if (k != OCREVT_ONCE && k != OCREVT_LATCH) atomicAdd(&d.ctrl->async_block, 1u); // persistent / counted / channel events: order matters
     const u32 hi = 0; s32 arg_val = 0;
     if (k == OCREVT_COUNTED) { // nbDeps > 0 (hc-event.c:1600-1612); the count lives in counted[x]
         if (arg[i] <= 0) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); d.evt[x] = EvtRec{0, 0, (u32)ST_ABSENT, 0}; return; }
@@ -1313,6 +1769,7 @@ __global__ void k_edt_create(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n, c
     if (i >= n) return;
     u32 e = take_index(rc.free_edt, n_free, n_take, first_idx, i), dc = depc[i], b = body[i] & 0xFFFFu;
     EdtGuids eg = {0, 0, 0, 0};
+    if (OCRBODY_KIND(b) != OCRBODY_NOP && OCRBODY_KIND(b) != OCRBODY_HASH) atomicAdd(&d.ctrl->async_block, 1u); // FWD0 / HOST / TILE bodies
     if ((OCRBODY_KIND(b) == OCRBODY_TILE && (dc > INLINE_SLOTS || !d.ctrl->tiles)) || (d.ctrl->dbl && dc > LOCKABLE_MAX_DEPC)) { // a TILE body reads its (<= 5) pre-slots from the line, and needs tile datablocks // acq_walk / release_all are quadratic in depc: refuse what would not finish (the EDT does not exist)
         atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); EdtLine Z; memset(&Z, 0, sizeof Z); Z.out_state = (u32)ST_ABSENT; d.edt[e] = Z; rc.edt_guids[e] = eg;
         if (!gin) { guids_out[i] = 0; if (outevt_out) outevt_out[i] = 0; if (outdb_out) outdb_out[i] = 0; }
@@ -1448,7 +1905,10 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
     u64 sv = gtab_get(d, s);
     u32 sk = OCRGPU_GUID_KIND(s);
     if (!sv) { atomicAdd(&d.ctrl->err[is_event_kind(sk) ? ERR_LATE_WAITER : ERR_BAD_OP], 1u); return; }
-    if (sk == OCRGPU_KIND_DB) { q_push(d, Rec{didx, (u32)sv, dslot, dflag | mnull}); return; } // mode recorded, then satisfy
+    if (sk == OCRGPU_KIND_DB) { // mode recorded, then satisfy
+        if ((u32)sv - 1 >= d.max_db && !(d.edt[(u32)sv - 1 - d.max_db].body & BODY_VAL_DONE)) atomicAdd(&d.ctrl->async_block, 1u); // the output datablock of an EDT that may never run: k_async would wait for its value
+        q_push(d, Rec{didx, (u32)sv, dslot, dflag | mnull}); return;
+    }
     if (!is_event_kind(sk)) { bad_op(d); return; }
     u32 x = (u32)(sv - 1);
     const u32 sw = *evt_state(d, x);
@@ -1500,6 +1960,8 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
     if ((u64)li + d.ctrl->chan_wait_used >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // waiters[] top end = CHANNEL rings
     d.log_src[li] = x;
     u32 dlatch = (!d_edt && OCRGPU_GUID_KIND(dst[i]) == OCRGPU_KIND_EVT_LATCH) ? RF_DST_LATCH : 0u;
+    // k_async takes EDT pre-slots whose payload word is already there and LATCH DECR slots (order-free); anything else is counted
+    if (d_edt ? !pre : (!dlatch || dslot != OCRLATCH_DECR)) atomicAdd(&d.ctrl->async_block, 1u);
     d.log_rec[li] = ((u64)(((dflag | mnull | pre | dlatch) << 28) | dslot) << 32) | (u64)didx;
 }
 
@@ -1517,6 +1979,7 @@ __global__ void k_satisfy(Dev d, u64 n, const u64 *evt, const u64 *db, const u32
     if (!resolve_dst(d, g, slot[i], didx, dflag, dslot)) { bad_op(d); return; }
     u32 pay = 0;
     if (db[i] != OCRGPU_NULL_GUID) { u64 v = gtab_get(d, db[i]); if (!v || OCRGPU_GUID_KIND(db[i]) != OCRGPU_KIND_DB) { bad_op(d); return; } pay = (u32)v; }
+    if (pay && pay - 1 >= d.max_db && !(d.edt[pay - 1 - d.max_db].body & BODY_VAL_DONE)) atomicAdd(&d.ctrl->async_block, 1u); // (as in k_add_dep)
     q_push(d, Rec{didx, pay, dslot, dflag});
 }
 
@@ -1536,7 +1999,7 @@ __global__ void k_set_scripts(Dev d, u64 n, const u64 *edt, const u32 *begin, co
     if (!v || OCRGPU_GUID_KIND(edt[i]) != OCRGPU_KIND_EDT) { bad_op(d); return; }
     u32 e = (u32)(v - 1);
     d.edt_script_begin[e] = script_base + begin[i]; d.edt_script_len[e] = len[i];
-    if (len[i]) d.edt[e].body |= BODY_F_SCRIPT;
+    if (len[i]) { d.edt[e].body |= BODY_F_SCRIPT; atomicAdd(&d.ctrl->async_block, 1u); } // a body's own satisfies: events whose order matters
 }
 __global__ void k_script_ops(Dev d, u64 n, const ocrgpu_script_op_t *ops, u32 script_base) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
@@ -1855,6 +2318,7 @@ __global__ void k_pop_ready(Dev d, u32 begin, u32 end, u32 max_edts, u32 max_dep
 __global__ void k_csr_clear(Dev d, u32 n_evt_total) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_evt_total) *evt_deg(d, i) = 0;
+    if (i == 0) d.ctrl->max_row = 0;
 }
 __global__ void k_csr_count(Dev d) {
     u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
@@ -1865,7 +2329,18 @@ __global__ void k_csr_count(Dev d) {
 }
 __global__ void k_csr_gather_deg(Dev d, u32 n, u32 *deg) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) deg[i] = *evt_deg(d, i);
+    u32 m = 0;
+    if (i < n) { deg[i] = *evt_deg(d, i); if (i >= d.max_evt) m = deg[i]; } // (rows of EDT output events: the ones k_async fans out in numbers)
+    for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_xor(m, o); m = x > m ? x : m; }
+    if (lane_id() == 0 && m > AMAX_ROW) atomicMax(&d.ctrl->max_row, m); // (only rows that matter to the choice of path cost an atomic)
+}
+// the first AROW waiters of every EDT's output event, beside the lines and indexed by EDT (k_async: one trip for line and row)
+__global__ void k_irow_fill(Dev d, u64 *irow, u32 n_edt) {
+    const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edt) return;
+    const u32 row = d.edt[e].out_row, deg = d.edt[e].out_deg;
+#pragma unroll
+    for (u32 k = 0; k < AROW; ++k) irow[(size_t)e * AROW + k] = k < deg ? d.waiters[row + k] : 0ull;
 }
 __global__ void k_csr_set_rows(Dev d, u32 n, const u32 *row, u32 *cursor) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2050,6 +2525,7 @@ __global__ void k_reclaim_finish(Dev d, ReclDev rc, u32 compact_log) {
 #define RP_ERR 4u      // pin[PIN_ERR..+8)    = Ctrl.err[]
 #define RP_QUEUE 8u    // pin[33008], [33009] = Ctrl.q_begin, q_tail
 #define RP_REND 16u    // pin[33010], [33011] = Ctrl.r_end, r_tail
+#define RP_ASYNC 32u   // pin[33040..33044]   = Ctrl.async_block, max_row, b_begin, b_end, level
 // (pin[33040..+8) = the four header sums of an exchange round, u64 each: written by exchange_finish)
 __global__ void k_report(Dev d, u32 K, u32 what, u32 *pin) {
     const u32 t = threadIdx.x;
@@ -2059,6 +2535,7 @@ __global__ void k_report(Dev d, u32 K, u32 what, u32 *pin) {
     if ((what & RP_ERR) && t < 8) pin[33020 + t] = c->err[t];
     if ((what & RP_QUEUE) && t == 0) { pin[33008] = c->q_begin; pin[33009] = c->q_tail; }
     if ((what & RP_REND) && t == 0) { pin[33010] = c->r_end; pin[33011] = c->r_tail; }
+    if ((what & RP_ASYNC) && t == 0) { pin[33040] = c->async_block; pin[33041] = c->max_row; pin[33042] = c->b_begin; pin[33043] = c->b_end; pin[33044] = c->level; }
 }
 
 // ---- result readback ------------------------------------------------------------------------------------
@@ -2150,6 +2627,8 @@ struct ocrgpu_engine {
     // reclaimed capacity (ocrgpu_reclaim, ocrgpu_db_destroy): device tables, host mirrors of the free-stack heights and of the
     // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
     ReclDev rc; u32 n_free_edt, n_free_evt, n_free_db, n_held; u64 mut_epoch; char *recl_tmp; size_t recl_tmp_cap;
+    // the barrier-free resolve (k_async): its tables (null = this engine never takes that path), launch shape, runs so far
+    ADev ad; u32 async_waves; u64 async_runs; int async_mode; // async_mode: 0 never, 1 when the DAG allows and looks narrow (default), 2 whenever it allows
 };
 
 static int dalloc(ocrgpu_engine *e, void **p, size_t bytes, bool zero = true) {
@@ -2233,7 +2712,7 @@ static int scan_u32(ocrgpu_engine *e, const u32 *in, u32 *out, u64 n, u32 add0, 
 }
 
 static int scratch_setup(int device);
-extern "C" int ocrgpu_abi_version(void) { return 3; }
+extern "C" int ocrgpu_abi_version(void) { return 4; }
 extern "C" const char *ocrgpu_last_error(void) { return g_err; }
 
 extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_config_t *cfg) {
@@ -2324,6 +2803,23 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&e->rc.held, 4 * (size_t)cfg->max_edt));
     TRY(dalloc(e, (void **)&e->rc.held_new, 4 * (size_t)cfg->max_edt));
     TRY(dalloc(e, (void **)&e->rc.cnt, 4 * RC_N));
+    memset(&e->ad, 0, sizeof e->ad); e->async_runs = 0; e->async_waves = 0;
+    { const char *am = getenv("OCRGPU_ASYNC"); e->async_mode = am ? atoi(am) : 1; }
+    if ((cfg->flags & (OCRGPU_F_NANNY | OCRGPU_F_LOCKABLE_DB | OCRGPU_F_WIDE_DB | OCRGPU_F_NO_ASYNC)) || d.max_levels > (1u << 24)) e->async_mode = 0;
+    if (e->async_mode) {
+        const u64 acap = (u64)cfg->max_edt + cfg->max_evt + 64;
+        if (acap < 0xFFFFFFF0ull) {
+            e->ad.cap = (u32)acap;
+            TRY(dalloc(e, (void **)&e->ad.c, sizeof(ACtl)));
+            TRY(dalloc(e, (void **)&e->ad.q, 8 * (size_t)ANSH * acap));
+            TRY(dalloc(e, (void **)&e->ad.irow, 8 * (size_t)AROW * cfg->max_edt));
+            TRY(dalloc(e, (void **)&e->ad.alat, 8 * (size_t)cfg->max_evt));
+            TRY(dalloc(e, (void **)&e->ad.hist, 4 * ((size_t)d.max_levels + 4)));
+            const char *w = getenv("OCRGPU_ASYNC_WAVES"), *rf = getenv("OCRGPU_ASYNC_REFILL");
+            e->async_waves = w ? (u32)atoi(w) : 1024u; if (e->async_waves < 8) e->async_waves = 8; if (e->async_waves > 8192) e->async_waves = 8192;
+            u32 r = rf ? (u32)atoi(rf) : 16u; e->ad.refill = r <= 8 ? 8u : r <= 16 ? 16u : 32u; // (a power of two: the wave's scans run over the ticket lanes)
+        } else e->async_mode = 0;
+    }
     // ctrl.level starts at -1 (main-program satisfies are "level -1")
     Ctrl h; memset(&h, 0, sizeof h); h.level = 0xFFFFFFFFu; h.state[0].done = h.state[1].done = 1;
     h.dbl = e->dbl; h.acq_mode = e->acq_mode; h.tiles = e->tiles;
@@ -2343,6 +2839,11 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     if (!e) return 0;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+#ifdef OCRGPU_ASTAMPS
+    { u64 g[16]; if (e->async_runs && hipMemcpy(g, e->d.dbg + 32, sizeof g, hipMemcpyDeviceToHost) == hipSuccess && g[0])
+        fprintf(stderr, "[k_async, %llu runs] wave-iterations %llu (%.1f items each); per iteration: %.2f us to the end of the hand-over (loads %.2f, fan-out %.2f, hand-over %.2f), body %.2f us (latch edges %.2f, gathers %.2f, %llu second looks); idle polls %llu\n",
+                (unsigned long long)e->async_runs, (unsigned long long)g[0], (double)g[4] / g[0], g[1] * 0.01 / g[0], g[6] * 0.01 / g[0], g[7] * 0.01 / g[0], g[5] * 0.01 / g[0], g[2] * 0.01 / g[0], g[9] * 0.01 / g[0], g[10] * 0.01 / g[0], (unsigned long long)g[8], (unsigned long long)g[3]); }
+#endif
 #ifdef OCRGPU_STAMPS
     { u64 h[16]; if (e->d.dbg && hipMemcpy(h, e->d.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
         fprintf(stderr, "[stamps, 10ns ticks of workgroup 0 summed over %llu launches] entry %llu | A(loads) %llu | scan %llu | fanout %llu | body %llu | ticket %llu\n",
@@ -2409,6 +2910,7 @@ static int seal(ocrgpu_engine *e) {
     if (r) return r;
     k_csr_set_rows<<<nblk(used), 256, 0, e->stream>>>(d, used, e->tmp_b, e->tmp_c);
     k_csr_fill<<<g, 256, 0, e->stream>>>(d, e->tmp_c);
+    if (e->async_mode && e->n_edt) k_irow_fill<<<nblk(e->n_edt), 256, 0, e->stream>>>(d, e->ad.irow, e->n_edt);
     HIPCHK(hipGetLastError());
     e->csr_dirty = false; ++e->seal_epoch;
     return 0;
@@ -2820,15 +3322,52 @@ static int fetch_stats(ocrgpu_engine *e, ocrgpu_stats_t *out) {
     HIPCHK(hipStreamSynchronize(e->stream));
     out->levels = h.n_levels;
     for (u32 b = 0; b < MAX_GRID; ++b) { out->edt_sat += bs[4 * b]; out->evt_sat += bs[4 * b + 1]; out->fired += bs[4 * b + 2]; }
-    out->launches = e->launches_total; out->step_kernel_ns = e->step_ns_total;
+    out->launches = e->launches_total; out->step_kernel_ns = e->step_ns_total; out->async_runs = e->async_runs;
     for (int i = 0; i < 8; ++i) out->err[i] = h.err[i];
+    return 0;
+}
+// The barrier-free resolve (k_async, see there), entered with the main program's satisfies applied (the queue of satisfy records
+// empty) and the EDTs they made ready as seeds.  One synchronisation at its end.
+static int run_async(ocrgpu_engine *e) {
+    Dev &d = e->d;
+    ADev a = e->ad; a.n_evt = e->n_evt;
+    const bool timing = e->have_events;
+    k_async_reset<<<1024, 256, 0, e->stream>>>(a);
+    k_async_init<<<1, 64, 0, e->stream>>>(d, a);
+    k_async_seed<<<256, 256, 0, e->stream>>>(d, a);
+    if (timing) HIPCHK(hipEventRecord(e->ev0, e->stream));
+    k_async<<<e->async_waves, 64, 0, e->stream>>>(d, a);
+    if (timing) HIPCHK(hipEventRecord(e->ev1, e->stream));
+    k_async_hist<<<1024, 256, 0, e->stream>>>(d, a);
+    k_async_scan<<<1, 1024, 0, e->stream>>>(d, a);
+    k_async_scatter<<<1024, 256, 0, e->stream>>>(d, a);
+    if (e->launch_index > 0xFFFF0000u) e->launch_index = 8;
+    const u32 K = ++e->launch_index;
+    k_async_end<<<64, 256, 0, e->stream>>>(d, a, K);
+    k_report<<<1, 64, 0, e->stream>>>(d, K, RP_STATE | RP_ERR, e->pinned_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (timing) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1)); e->step_ns_total += (u64)(ms * 1e6); }
+    ++e->launches_total; ++e->async_runs;
     return 0;
 }
 extern "C" int ocrgpu_resolve(ocrgpu_engine_t *e, u64 max_levels, ocrgpu_stats_t *stats_out) {
     ENTER(e);
     u64 max_launches = max_levels ? 4 * max_levels + 64 : ~0ull;
-    int r = run_steps(e, 0xFFFFFFFFu, max_launches, true);
-    if (r) return r;
+    int r;
+    bool done = false;
+    if (e->async_mode && !max_levels && e->d.n_loc <= 1 && !e->defer_drain) {
+        // apply what the main program queued (EVENTS phases only: nothing fires), then look at what is ready and at what the DAG is made of
+        r = run_steps(e, 0u, ~0ull, false);
+        if (r) return r;
+        k_report<<<1, 64, 0, e->stream>>>(e->d, 0u, RP_QUEUE | RP_REND | RP_ASYNC | RP_ERR, e->pinned_dev);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        const u32 *pn = e->pinned_done;
+        const u32 seeds = pn[33011] - pn[33010];
+        const bool clean = pn[33040] == 0 && pn[33009] <= pn[33008] && pn[33043] <= pn[33042] && pn[33044] + 2u < e->d.max_levels;
+        if (clean && seeds && pn[33041] <= AMAX_ROW && (e->async_mode >= 2 || seeds <= AMAX_SEEDS)) { r = run_async(e); if (r) return r; done = true; }
+    }
+    if (!done) { r = run_steps(e, 0xFFFFFFFFu, max_launches, true); if (r) return r; }
     if (stats_out) { r = fetch_stats(e, stats_out); if (r) return r; e->last = *stats_out; }
     return check_fault(e); // stats_out is filled either way
 }

@@ -22,6 +22,7 @@ HOST, DEVICE = 0, 1
 GUIDS_GIVEN = 4   # OR into `where` of the create calls: guid arrays are inputs (ocrgpu.h)
 F_NANNY, F_TIMING = 1, 2
 F_WIDE_DB = 16     # datablocks carry an 8x8 int64 tile that OCRBODY_TILE bodies update in place
+F_NO_ASYNC = 32    # ocrgpu_resolve always level by level (by default an eligible, narrow DAG resolves as one barrier-free kernel)
 F_LOCKABLE_DB = 8  # datablocks arbitrate their acquire modes (the cfg's datablockfactory=Lockable)
 EFAULT = -14       # OCRGPU_EFAULT: the device flagged a user-level error during the call (which completed)
 
@@ -55,11 +56,11 @@ class Reclaim(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("levels", C.c_uint64), ("fired", C.c_uint64), ("edt_sat", C.c_uint64), ("evt_sat", C.c_uint64),
-                ("launches", C.c_uint64), ("step_kernel_ns", C.c_uint64), ("err", C.c_uint64 * 8)]
+                ("launches", C.c_uint64), ("step_kernel_ns", C.c_uint64), ("err", C.c_uint64 * 8), ("async_runs", C.c_uint64)]
 
     def as_dict(self):
         return dict(levels=self.levels, fired=self.fired, edt_sat=self.edt_sat, evt_sat=self.evt_sat,
-                    launches=self.launches, step_kernel_ns=self.step_kernel_ns, err=list(self.err))
+                    launches=self.launches, step_kernel_ns=self.step_kernel_ns, err=list(self.err), async_runs=self.async_runs)
 
 
 SCRIPT_OP_DT = np.dtype([("target", "<u8"), ("payload", "<u8"), ("slot", "<u4"), ("op", "u1"), ("payload_kind", "u1"),
