@@ -1258,24 +1258,22 @@ __global__ void k_end(Dev d, u32 K) { end_of_run(d, K); }
 // Values: a body publishes its value with one 8-byte sc1 store; a consumer's body gathers its producers' {param0, val} with
 // 16-byte sc1 loads and looks again in the rare case a value is still 0 (the body runs behind the hand-over of the EDTs its
 // wave made ready, so nothing on the dependence path waits for a value).
-#ifndef OCRGPU_AEXP
-#define OCRGPU_AEXP 0
-#endif
 #define ANSH 8u             // queue shards (a wave takes tickets from shard wave % 8 and hands over to shard (wave + iteration) % 8)
 #define AROW 8u             // waiters of an EDT's output event kept beside the line, indexed by EDT (Dev-free: ADev.irow)
 #define A_EVT 0x80000000u   // queue entry id: a fired event (index + 1) instead of a ready EDT (index + 1)
 #define A_OUT 512u          // ready entries a wave collects before it hands them over
+#define A_SKIP 0xFFFFFFFFu   // queue entry id: padding of a hand-over's last block (the ticket is served, there is nothing to fire)
+#define A_BK 1024u          // ready entries a wave can keep for itself when the queues are full
 #define ALAT_BIAS 0x40000000u
 #define AMAX_ROW 1024u      // rows longer than this: level-synchronous path (its big-row pieces spread over the grid)
 #define AMAX_SEEDS 65536u   // more ready EDTs than this at the start: a wide DAG, atomic-rate bound, better served level by level
 struct alignas(128) AShard { u32 tail; u32 p0[31]; u32 head; u32 p1[31]; u64 acct; u32 p2[30]; }; // acct = entries consumed << 32 | busy waves
 struct ACtl { AShard sh[ANSH]; u32 old_tail[ANSH]; u32 L0, seed_begin, seed_end, max_level, n_lv_prev, total_out, pad[2]; };
-struct ADev { ACtl *c; u64 *q; u64 *irow; u64 *alat; u32 *hist; u32 cap, refill, n_evt, pad; };
+struct ADev { ACtl *c; u64 *q; u64 *irow; u64 *alat; u32 *hist; u32 cap, refill /* scan width: a power of two >= blk */, n_evt, blk /* entries per block = tickets a wave takes */; };
 
 __device__ __forceinline__ u32 a_ld(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 a_ld(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void a_st16(void *p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 // Eight 16-byte sc1 loads in flight, one wait (which also covers what the wave issued before the block).  Load k is made by the
 // lanes of mask m[k] only (EXEC is narrowed around it): a wave holds about 14 EDTs with 4 pre-slots each, and the idle lanes and
 // unused pre-slots would otherwise put seven times as many requests on the fabric as the real ones.  g[k] of a lane outside m[k] is
@@ -1304,7 +1302,7 @@ __device__ bool a_quiescent(const ADev &a) {
     if (lane < ANSH) { x = a_ld(&a.c->sh[lane].acct); tx = a_ld(&a.c->sh[lane].tail); }
     if (lane < ANSH) { y = a_ld(&a.c->sh[lane].acct); ty = a_ld(&a.c->sh[lane].tail); }
     if (__ballot(x != y || tx != ty)) return false;
-    u64 cons = x >> 32, busy = x & 0xFFFFFFFFull, tl = tx;
+    u64 cons = x >> 32, busy = x & 0xFFFFFFFFull, tl = tx < a.cap ? tx : a.cap; // (what was reserved beyond a shard's end is never written)
     for (int o = 1; o < (int)ANSH; o <<= 1) { cons += __shfl_xor(cons, o); busy += __shfl_xor(busy, o); tl += __shfl_xor(tl, o); }
     cons = __shfl(cons, 0); busy = __shfl(busy, 0); tl = __shfl(tl, 0);
     return (busy & 0xFFFFFFFFull) == 0 && cons == tl;
@@ -1371,67 +1369,100 @@ __device__ void a_latches(const Dev &d, const ADev &a, const u32 *lds_lat, u32 n
     }
 }
 
+#ifdef OCRGPU_ASTAMPS
+static __device__ unsigned long long g_ats[ANSH << 20]; // when an entry was handed over (10 ns ticks), by shard and entry index mod 2^20
+#endif
 __global__ __launch_bounds__(64) void k_async(Dev d, ADev a) {
     __shared__ u64 lds_w[AROW * 32];
     __shared__ u32 lds_l[AROW * 32];
     __shared__ u32 lds_id[A_OUT], lds_lv[A_OUT];
     __shared__ u32 lds_lat[2 * A_LAT];
-    const u32 lane = threadIdx.x, wid = blockIdx.x, sh = wid & (ANSH - 1u);
+    __shared__ u32 lds_bk[2 * A_BK];
+    const u32 lane = threadIdx.x, wid = blockIdx.x, sh = wid & (ANSH - 1u), B = a.blk;
     ACtl *c = a.c;
-    AShard *S = &c->sh[sh];
-    const u64 *Q = a.q + (size_t)sh * a.cap;
-    u32 item = INVALID, lvl = 0, ticket = INVALID, spins = 0, iter = 0, max_lv = 0;
-    bool busy = false; // (wave-uniform) this wave is counted in its shard's busy total
+    u32 csh = sh, busy_sh = sh, dead = 0;         // the shard this wave takes tickets from; the one it is counted busy on; shards found used up
+    u32 item = INVALID, lvl = 0, ticket = INVALID, spins = 0, iter = 0, max_lv = 0, sink = 0, nbk = 0;
+    bool busy = false; // (wave-uniform) this wave is counted in a shard's busy total
     u64 n_edt_sat = 0, n_evt_sat = 0, n_fired = 0;
 #ifdef OCRGPU_ASTAMPS
-    u64 s_iter = 0, s_titer = 0, s_tbody = 0, s_idle = 0, s_items = 0, s_thand = 0, s_tload = 0, s_tfan = 0, s_lat = 0, s_tlat = 0, s_tgat = 0;
+    u64 s_iter = 0, s_titer = 0, s_tbody = 0, s_idle = 0, s_items = 0, s_thand = 0, s_tload = 0, s_tfan = 0, s_lat = 0, s_tlat = 0, s_tgat = 0, s_thop = 0, s_nhop = 0, t_ready = 0; u32 last_ticket = INVALID;
 #define ASTAMP(x) x
 #else
 #define ASTAMP(x)
 #endif
-    // hand the collected entries to a queue: one returning add reserves, the entries go out as 8-byte sc1 stores
+    // Hand the collected entries to a queue: one returning add reserves whole BLOCKS of B entries (the last one padded with A_SKIP),
+    // the entries go out as 8-byte sc1 stores.  A consumer takes B tickets = one block = what ONE wave wrote in one go: its batch
+    // arrives together (tickets that straddled two hand-overs left entries waiting for a wave already at work: 9.5 -> 7.9 ms).
+    // A queue that is used up cannot take the entries: the wave keeps them and fires them itself (depth first, as the reference does).
     auto hand_over = [&](u32 &nready) {
         if (nready > A_OUT) nready = A_OUT; // (cannot happen: the callers flush in time)
         if (!nready) return;
-        const u32 tsh = (sh + iter) & (ANSH - 1u);
+        const u32 tsh = (sh + iter) & (ANSH - 1u), nb = (nready + B - 1u) / B * B;
         u32 qb = 0;
-        if (lane == 0) qb = atomicAdd(&c->sh[tsh].tail, nready);
+        if (lane == 0) qb = atomicAdd(&c->sh[tsh].tail, nb);
         qb = __shfl(qb, 0);
         u64 *QT = a.q + (size_t)tsh * a.cap;
-        for (u32 i = lane; i < nready; i += 64) {
-            if (qb + i < a.cap) __hip_atomic_store(&QT[qb + i], ((u64)lds_lv[i] << 32) | (u64)lds_id[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+        if ((u64)qb + nb <= a.cap) {
+            ASTAMP(for (u32 i = lane; i < nb; i += 64) g_ats[((size_t)tsh << 20) + ((qb + i) & 0xFFFFFu)] = t_ready);
+            for (u32 i = lane; i < nb; i += 64)
+                __hip_atomic_store(&QT[qb + i], i < nready ? (((u64)lds_lv[i] << 32) | (u64)lds_id[i]) : (u64)A_SKIP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (u32 i = lane; i < nb; i += 64) if (qb + i < a.cap) __hip_atomic_store(&QT[qb + i], (u64)A_SKIP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (u32 i = lane; i < nready; i += 64) {
+                if (nbk + i < A_BK) { lds_bk[2 * (nbk + i)] = lds_id[i]; lds_bk[2 * (nbk + i) + 1] = lds_lv[i]; }
+                else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+            }
+            nbk = nbk + nready < A_BK ? nbk + nready : A_BK;
         }
         nready = 0;
     };
     for (;;) {
+        const u64 *Q = a.q + (size_t)csh * a.cap;
         bool got = false;
-        if (ticket != INVALID) { const u64 v = a_ld(&Q[ticket]); if ((u32)v) { item = (u32)v; lvl = (u32)(v >> 32); ticket = INVALID; got = true; } }
-        const u64 gm = __ballot(got), hm = __ballot(item != INVALID);
+        for (u32 g = 0; g < 64; ++g) { // a block's entries arrive together, give or take the skew of one wave's stores: look until all are there
+            if (ticket != INVALID) { const u64 v = a_ld(&Q[ticket]); if ((u32)v) { if ((u32)v != A_SKIP) { item = (u32)v; lvl = (u32)(v >> 32); } ticket = INVALID; got = true; } }
+            if (!__ballot(got) || !__ballot(ticket != INVALID)) break;
+        }
+        const u64 gm = __ballot(got);
+        u64 hm = __ballot(item != INVALID);
         if (gm) { // entries consumed (+ idle -> busy) in ONE atomic: "consumed" never shows without the "busy" that goes with it
-            if (lane == 0) atomicAdd((unsigned long long *)&S->acct, ((unsigned long long)__popcll(gm) << 32) + (busy ? 0ull : 1ull));
-            busy = true;
+            const bool nb = hm != 0 && !busy;
+            if (lane == 0) atomicAdd((unsigned long long *)&c->sh[csh].acct, ((unsigned long long)__popcll(gm) << 32) + (nb ? 1ull : 0ull));
+            if (nb) { busy = true; busy_sh = csh; }
+        }
+        if (!hm && nbk && !__ballot(ticket != INVALID)) { // entries this wave had to keep: it fires them itself
+            const u32 take = nbk < B ? nbk : B;
+            if (lane < take) { item = lds_bk[2 * (nbk - take + lane)]; lvl = lds_bk[2 * (nbk - take + lane) + 1]; }
+            nbk -= take;
+            hm = __ballot(item != INVALID);
+            __syncthreads();
         }
         if (!hm) {
-            if (busy) { if (lane == 0) atomicAdd((unsigned long long *)&S->acct, ~0ull); busy = false; } // (behind the hand-over's returned add)
-            const u64 fm = __ballot(lane < a.refill && ticket == INVALID);
-            if ((u32)__popcll(fm) * 2 >= a.refill) { // at least half of the ticket lanes are free: take tickets for them
+            if (busy && !nbk) { if (lane == 0) atomicAdd((unsigned long long *)&c->sh[busy_sh].acct, ~0ull); busy = false; } // (behind the hand-over's returned add)
+            if (!__ballot(ticket != INVALID)) { // (a block's tickets are served together: none is left when the wave comes back)
+                if (dead >= ANSH) { // every queue is used up: nothing more can reach this wave
+                    ++spins;
+                    if ((spins & 7u) == 0 && a_quiescent(a)) break;
+                    __builtin_amdgcn_s_sleep(64);
+                    continue;
+                }
                 u32 base = 0;
-                if (lane == 0) base = atomicAdd(&S->head, (u32)__popcll(fm));
+                if (lane == 0) base = atomicAdd(&c->sh[csh].head, B);
                 base = __shfl(base, 0);
-                if (lane < a.refill && ticket == INVALID && base + rank_in(fm) < a.cap) ticket = base + rank_in(fm);
-                if (base >= a.cap) { if (a_quiescent(a)) break; __builtin_amdgcn_s_sleep(64); }
+                if ((u64)base + B <= a.cap) { if (lane < B) ticket = base + lane; ASTAMP(last_ticket = base); }
+                else { ++dead; csh = (csh + 1u) & (ANSH - 1u); }
                 continue;
             }
             // waiting: every wave polls its OWN ticket words (polling a shared word from hundreds of waves slows every request that
             // shares its channel: measured); the shared totals are looked at rarely
             ++spins; ASTAMP(++s_idle);
             if ((spins & 31u) == 0 && a_quiescent(a)) break;
-            if (spins < 8) __builtin_amdgcn_s_sleep(2); else if (spins < 32) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(32);
+            if (spins < 8) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(8);
             continue;
         }
         spins = 0; ++iter;
         ASTAMP(const u64 t_in = __builtin_amdgcn_s_memrealtime(); ++s_iter; s_items += __popcll(hm));
+        ASTAMP(if (gm && lane == 0 && last_ticket != INVALID) { const u64 ts = g_ats[((size_t)csh << 20) + (last_ticket & 0xFFFFFu)]; if (ts && t_in > ts && t_in - ts < 100000) { s_thop += t_in - ts; ++s_nhop; } });
         const bool has = item != INVALID, is_evt = has && (item & A_EVT) != 0, is_edt = has && !is_evt;
         const u32 idx = has ? (item & ~A_EVT) - 1u : 0u;
         // ---- one trip: the EDT's line and its inline waiter row (both addressed by the EDT's index alone) ----
@@ -1495,7 +1526,7 @@ __global__ __launch_bounds__(64) void k_async(Dev d, ADev a) {
             a_collect(e0, lds_id, lds_lv, lds_lat, nready, nlat, n_edt_sat, n_evt_sat);
         }
         __syncthreads();
-        ASTAMP(const u64 t_fan = __builtin_amdgcn_s_memrealtime(); s_tfan += t_fan - t_ld);
+        ASTAMP(const u64 t_fan = __builtin_amdgcn_s_memrealtime(); s_tfan += t_fan - t_ld; t_ready = t_fan);
         hand_over(nready);
         ASTAMP(const u64 t_ho = __builtin_amdgcn_s_memrealtime(); s_thand += t_ho - t_fan; s_titer += t_ho - t_in);
         // ---- behind the hand-over: the latch edges, then the body (taskExecute's user function; the epilogue's output-event satisfy
@@ -1555,7 +1586,7 @@ __global__ __launch_bounds__(64) void k_async(Dev d, ADev a) {
     }
 #ifdef OCRGPU_ASTAMPS
     if (lane == 0) { unsigned long long *g = (unsigned long long *)d.dbg + 32; atomicAdd(g, s_iter); atomicAdd(g + 1, s_titer); atomicAdd(g + 2, s_tbody); atomicAdd(g + 3, s_idle);
-                     atomicAdd(g + 4, s_items); atomicAdd(g + 5, s_thand); atomicAdd(g + 6, s_tload); atomicAdd(g + 7, s_tfan); atomicAdd(g + 8, s_lat); atomicAdd(g + 9, s_tlat); atomicAdd(g + 10, s_tgat); }
+                     atomicAdd(g + 4, s_items); atomicAdd(g + 5, s_thand); atomicAdd(g + 6, s_tload); atomicAdd(g + 7, s_tfan); atomicAdd(g + 8, s_lat); atomicAdd(g + 9, s_tlat); atomicAdd(g + 10, s_tgat); atomicAdd(g + 11, s_thop); atomicAdd(g + 12, s_nhop); }
 #endif
     if (lane == 0) {
         if (n_edt_sat | n_evt_sat | n_fired) {
@@ -1587,17 +1618,21 @@ __global__ void k_async_seed(Dev d, ADev a) {
     ACtl *c = a.c;
     const u64 gs = (u64)gridDim.x * blockDim.x, t0 = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     for (u64 x = t0; x < a.n_evt; x += gs) if (((d.evt[x].state_kind >> 8) & 0xFF) == OCREVT_LATCH) a.alat[x] = (u64)((u32)d.evt[x].val + ALAT_BIAS);
-    const u32 b = c->seed_begin, n = c->seed_end - b;
+    const u32 b = c->seed_begin, n = c->seed_end - b, B = a.blk;
     for (u64 i0 = (t0 & ~63ull); i0 < n; i0 += gs) { // (whole waves stay together: the append below is wave-wide)
         const u64 i = i0 + (t0 & 63u);
         const u32 e = i < n ? d.fired[b + i] : INVALID;
         const u32 s = (u32)((i0 / 64) % ANSH);
         const u64 m = __ballot(e != INVALID);
         if (!m) continue;
+        const u32 cnt = (u32)__popcll(m), nb = (cnt + B - 1u) / B * B; // whole blocks, the last one padded
         u32 base = 0; const int leader = __ffsll((long long)m) - 1;
-        if ((int)lane_id() == leader) base = atomicAdd(&c->sh[s].tail, (u32)__popcll(m));
+        if ((int)lane_id() == leader) base = atomicAdd(&c->sh[s].tail, nb);
         base = __shfl(base, leader);
+        if ((u64)base + nb > a.cap) { if ((int)lane_id() == leader) atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); continue; }
         if (e != INVALID) a.q[(size_t)s * a.cap + base + rank_in(m)] = ((u64)c->L0 << 32) | (u64)(e + 1u);
+        const u32 pad = nb - cnt;
+        if (lane_id() < pad) a.q[(size_t)s * a.cap + base + cnt + lane_id()] = (u64)A_SKIP;
     }
 }
 // after the run: the fired log grouped by level, from the queue entries (every EDT that fired is exactly one entry)
@@ -2807,7 +2842,10 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     { const char *am = getenv("OCRGPU_ASYNC"); e->async_mode = am ? atoi(am) : 1; }
     if ((cfg->flags & (OCRGPU_F_NANNY | OCRGPU_F_LOCKABLE_DB | OCRGPU_F_WIDE_DB | OCRGPU_F_NO_ASYNC)) || d.max_levels > (1u << 24)) e->async_mode = 0;
     if (e->async_mode) {
-        const u64 acap = (u64)cfg->max_edt + cfg->max_evt + 64;
+        const char *w = getenv("OCRGPU_ASYNC_WAVES"), *rf = getenv("OCRGPU_ASYNC_BLOCK");
+        u32 blk = rf ? (u32)atoi(rf) : 24u; if (blk < 4) blk = 4; if (blk > 32) blk = 32;
+        // entries per shard (8 shards), whole blocks: room for blocks filled to an eighth; a used-up queue makes waves keep what they make ready
+        const u64 acap = (((u64)cfg->max_edt + cfg->max_evt) / 2 + 65536) / blk * blk;
         if (acap < 0xFFFFFFF0ull) {
             e->ad.cap = (u32)acap;
             TRY(dalloc(e, (void **)&e->ad.c, sizeof(ACtl)));
@@ -2815,9 +2853,8 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
             TRY(dalloc(e, (void **)&e->ad.irow, 8 * (size_t)AROW * cfg->max_edt));
             TRY(dalloc(e, (void **)&e->ad.alat, 8 * (size_t)cfg->max_evt));
             TRY(dalloc(e, (void **)&e->ad.hist, 4 * ((size_t)d.max_levels + 4)));
-            const char *w = getenv("OCRGPU_ASYNC_WAVES"), *rf = getenv("OCRGPU_ASYNC_REFILL");
-            e->async_waves = w ? (u32)atoi(w) : 1024u; if (e->async_waves < 8) e->async_waves = 8; if (e->async_waves > 8192) e->async_waves = 8192;
-            u32 r = rf ? (u32)atoi(rf) : 16u; e->ad.refill = r <= 8 ? 8u : r <= 16 ? 16u : 32u; // (a power of two: the wave's scans run over the ticket lanes)
+            e->async_waves = w ? (u32)atoi(w) : 1280u; // (5 single-wave workgroups per CU; 1024 .. 1536 measure alike) if (e->async_waves < 8) e->async_waves = 8; if (e->async_waves > 8192) e->async_waves = 8192;
+            e->ad.blk = blk; e->ad.refill = blk <= 8 ? 8u : blk <= 16 ? 16u : 32u; // (a power of two: the wave's scans run over the ticket lanes)
         } else e->async_mode = 0;
     }
     // ctrl.level starts at -1 (main-program satisfies are "level -1")
@@ -2841,8 +2878,8 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     (void)hipStreamSynchronize(e->stream);
 #ifdef OCRGPU_ASTAMPS
     { u64 g[16]; if (e->async_runs && hipMemcpy(g, e->d.dbg + 32, sizeof g, hipMemcpyDeviceToHost) == hipSuccess && g[0])
-        fprintf(stderr, "[k_async, %llu runs] wave-iterations %llu (%.1f items each); per iteration: %.2f us to the end of the hand-over (loads %.2f, fan-out %.2f, hand-over %.2f), body %.2f us (latch edges %.2f, gathers %.2f, %llu second looks); idle polls %llu\n",
-                (unsigned long long)e->async_runs, (unsigned long long)g[0], (double)g[4] / g[0], g[1] * 0.01 / g[0], g[6] * 0.01 / g[0], g[7] * 0.01 / g[0], g[5] * 0.01 / g[0], g[2] * 0.01 / g[0], g[9] * 0.01 / g[0], g[10] * 0.01 / g[0], (unsigned long long)g[8], (unsigned long long)g[3]); }
+        fprintf(stderr, "[k_async, %llu runs] wave-iterations %llu (%.1f items each); per iteration: %.2f us to the end of the hand-over (loads %.2f, fan-out %.2f, hand-over %.2f), body %.2f us (latch edges %.2f, gathers %.2f, %llu second looks); idle polls %llu; atomics back -> taken up by the next wave %.2f us\n",
+                (unsigned long long)e->async_runs, (unsigned long long)g[0], (double)g[4] / g[0], g[1] * 0.01 / g[0], g[6] * 0.01 / g[0], g[7] * 0.01 / g[0], g[5] * 0.01 / g[0], g[2] * 0.01 / g[0], g[9] * 0.01 / g[0], g[10] * 0.01 / g[0], (unsigned long long)g[8], (unsigned long long)g[3], g[12] ? g[11] * 0.01 / g[12] : 0.0); }
 #endif
 #ifdef OCRGPU_STAMPS
     { u64 h[16]; if (e->d.dbg && hipMemcpy(h, e->d.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
