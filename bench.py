@@ -108,6 +108,12 @@ def main():
         dt = float(t.item())
     step_kernel_s = (eng.stats().step_kernel_ns - k0) * 1e-9 / args.steps
     launches = (eng.stats().launches - l0) / args.steps
+    # which worker loop ran: the barrier-free kernel (k_async: ONE launch fires the whole DAG; the launches before it only apply the
+    # main program's satisfy and are not in the kernel time) or one k_step launch per level
+    barrier_free = eng.stats().async_runs >= args.steps
+    kernel_launches = 1.0 if barrier_free else launches
+    kernel_name = ("k_async (the one launch of a resolve, HIP events on the engine stream)" if barrier_free
+                   else "k_step (all launches of one resolve, HIP events on the engine stream)")
 
     n_sat = s.meta["n_satisfactions"]          # EDT pre-slot + latch pre-slot satisfies per resolve
     assert st.fired == s.n_edt, (st.fired, s.n_edt)
@@ -139,13 +145,15 @@ def main():
                                    f"one independent partition per GPU",
                        "n_edt": s.n_edt, "n_satisfactions": n_sat, "levels": int(st.levels),
                        "edts_fired_per_s": s.n_edt * world / (dt / args.steps), "build_s": round(build_s, 2),
-                       "k_step_launches_per_resolve": launches, "parity": parity},
+                       "worker_loop": "barrier-free (k_async)" if barrier_free else "level-synchronous (k_step)",
+                       "launches_per_resolve": launches, "parity": parity},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / step_kernel_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": alg_bytes / step_kernel_s / 1e9 / 8000.0,
-                         "traffic": profiled_traffic(args)[0], "traffic_source": profiled_traffic(args)[1],
-                         "kernel": "k_step (all launches of one resolve, HIP events on the engine stream)",
-                         "launches_per_resolve": launches, "alg_bytes_per_launch": alg_bytes / launches,
-                         "us_per_launch": step_kernel_s / launches * 1e6,
+                         "traffic": profiled_traffic(args, kernel="k_async" if barrier_free else "k_step")[0],
+                         "traffic_source": profiled_traffic(args, kernel="k_async" if barrier_free else "k_step")[1],
+                         "kernel": kernel_name,
+                         "launches_per_resolve": kernel_launches, "alg_bytes_per_launch": alg_bytes / kernel_launches,
+                         "us_per_launch": step_kernel_s / kernel_launches * 1e6,
                          "alg_bytes_per_resolve": alg_bytes, "kernel_s_per_resolve": step_kernel_s},
         }
         # the limit that actually binds scattered slot counting (SURVEY.md s8d "second roofline"): returning device-scope
@@ -410,11 +418,11 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     dist.destroy_process_group()
 
 
-PROFILE_TAG = "r02j_config2"
+PROFILE_TAG = "r03a_config2"
 
 
-def profiled_traffic(args, tag=PROFILE_TAG):
-    """HBM bytes per k_step launch from the committed PMC passes (profiles/<tag>_pmc_summary.txt: FETCH_SIZE and
+def profiled_traffic(args, tag=PROFILE_TAG, kernel="k_step"):
+    """HBM bytes per launch of the dominant kernel (k_async, or k_step) from the committed PMC passes (profiles/<tag>_pmc_summary.txt: FETCH_SIZE and
     WRITE_SIZE in KB, separate rocprofv3 --pmc runs of this same workload).  Counters cannot be read inside this
     process, so the figure is the profiled one, and it is only quoted for the workload and the engine source it was
     taken on: the summary records a hash of ocr_amd/csrc/ocrgpu.hip, and any other source (or workload shape) gives
@@ -430,7 +438,7 @@ def profiled_traffic(args, tag=PROFILE_TAG):
             if line.startswith("source:"):
                 src = line.strip().split("=")[-1]
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-                if "k_step" in line and ctr + " sum=" in line:
+                if kernel in line and ctr + " sum=" in line:
                     kb[ctr] = float(line.split("per dispatch ")[1].rstrip(")\n"))
         now = hashlib.sha256(open(os.path.join(here, "ocr_amd", "csrc", "ocrgpu.hip"), "rb").read()).hexdigest()[:16]
     except OSError:

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <chrono>
 #include <algorithm>
 #include <dlfcn.h>
 #include <time.h>
@@ -1249,8 +1250,8 @@ __global__ void k_end(Dev d, u32 K) { end_of_run(d, K); }
 // per-level fired SETS stay exact because the level is data: level(EDT) = 1 + max level(its satisfiers), kept with an atomicMax
 // on EdtLine.level issued in FRONT of the returning add on EdtLine.pending of the same 8-byte word -- the add that takes pending to
 // zero brings the final level back -- which is what the replay harness's Lamport clock does on the reference
-// (oracle/ocr_replay.c:167-181).  The fired log is rebuilt grouped by level when the kernel has ended (k_async_hist / _scan /
-// _scatter), so everything behind ocrgpu_resolve reads what it always read.
+// (oracle/ocr_replay.c:167-181).  The fired log is rebuilt grouped by level when the kernel has ended (k_async_group<false> / k_async_scan /
+// k_async_group<true>), so everything behind ocrgpu_resolve reads what it always read.
 // What may run this way (anything else takes the level-synchronous path): one partition, no NANNY / Lockable / tile engine; only
 // ONCE and LATCH events; NOP / HASH bodies without scripts; every registered dependence either an EDT pre-slot whose payload word
 // was written at registration (RF_PREFILLED) or a LATCH DECR slot -- objects whose firing does not depend on the order of their
@@ -1635,27 +1636,59 @@ __global__ void k_async_seed(Dev d, ADev a) {
         if (lane_id() < pad) a.q[(size_t)s * a.cap + base + cnt + lane_id()] = (u64)A_SKIP;
     }
 }
-// after the run: the fired log grouped by level, from the queue entries (every EDT that fired is exactly one entry)
-__global__ void k_async_hist(Dev d, ADev a) {
+// after the run: the fired log grouped by level, from the queue entries (every EDT that fired is exactly one entry).
+// Queue order follows level order loosely, so a stretch of AGRP_CH consecutive entries holds a handful of levels: a workgroup
+// counts its stretch in LDS over a window of AGRP_WIN levels from the lowest it sees and goes to memory once per level it met
+// (SCATTER: with the returning atomic that hands the stretch its place in that level).  Levels beyond the window go one by one.
+#define AGRP_PER 16u
+#define AGRP_CH (256u * AGRP_PER)
+#define AGRP_WIN 256u
+template <bool SCATTER> __global__ __launch_bounds__(256) void k_async_group(Dev d, ADev a) {
+    __shared__ u32 cnt[AGRP_WIN], base_w[AGRP_WIN], lo_s;
     const ACtl *c = a.c;
-    const u64 gs = (u64)gridDim.x * blockDim.x, t0 = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    for (u32 s = 0; s < ANSH; ++s) {
-        const u32 n = c->sh[s].tail < a.cap ? c->sh[s].tail : a.cap;
-        for (u64 i0 = (t0 & ~63ull); i0 < n; i0 += gs) {
-            const u64 i = i0 + (t0 & 63u);
-            const u64 v = i < n ? a.q[(size_t)s * a.cap + i] : 0ull;
-            const u32 id = (u32)v, lv = (u32)(v >> 32);
-            bool mine = id != 0 && !(id & A_EVT) && lv > c->L0;
-            if (mine && lv >= d.max_levels) { atomicAdd(&d.ctrl->err[ERR_LEVEL_OVERFLOW], 1u); mine = false; }
-            u64 todo = __ballot(mine);
-            while (todo) { // one atomic per distinct level per wave
-                const int leader = __ffsll((long long)todo) - 1;
-                const u32 l0 = __shfl(lv, leader);
-                const u64 grp = __ballot(mine && lv == l0) & todo;
-                if ((int)lane_id() == leader) atomicAdd(&a.hist[l0 - c->L0 - 1u], (u32)__popcll(grp));
-                todo &= ~grp;
+    const u32 L0 = c->L0, t = threadIdx.x;
+    u32 n_s[ANSH], first[ANSH + 1]; first[0] = 0;
+    for (u32 s = 0; s < ANSH; ++s) { n_s[s] = c->sh[s].tail < a.cap ? c->sh[s].tail : a.cap; first[s + 1] = first[s] + (n_s[s] + AGRP_CH - 1u) / AGRP_CH; }
+    for (u32 g = blockIdx.x; g < first[ANSH]; g += gridDim.x) {
+        u32 s = 0; while (g >= first[s + 1]) ++s;
+        const u32 i0 = (g - first[s]) * AGRP_CH;
+        const u64 *q = a.q + (size_t)s * a.cap;
+        u32 id[AGRP_PER], lv[AGRP_PER], rk[AGRP_PER]; u32 lo = 0xFFFFFFFFu;
+        cnt[t] = 0; if (t == 0) lo_s = 0xFFFFFFFFu;
+#pragma unroll
+        for (u32 k = 0; k < AGRP_PER; ++k) {
+            const u32 i = i0 + k * 256u + t;
+            const u64 v = i < n_s[s] ? q[i] : 0ull;
+            id[k] = (u32)v; lv[k] = (u32)(v >> 32);
+            bool mine = id[k] != 0 && !(id[k] & A_EVT) && lv[k] > L0;
+            if (mine && lv[k] >= d.max_levels) { if (!SCATTER) atomicAdd(&d.ctrl->err[ERR_LEVEL_OVERFLOW], 1u); mine = false; }
+            if (!mine) id[k] = 0; else if (lv[k] < lo) lo = lv[k];
+        }
+        for (int o = 1; o < 64; o <<= 1) { const u32 n = __shfl_xor(lo, o); lo = n < lo ? n : lo; }
+        __syncthreads();
+        if ((t & 63u) == 0 && lo != 0xFFFFFFFFu) atomicMin(&lo_s, lo);
+        __syncthreads();
+        lo = lo_s;
+#pragma unroll
+        for (u32 k = 0; k < AGRP_PER; ++k) {
+            if (!id[k]) continue;
+            const u32 w = lv[k] - lo;
+            if (w < AGRP_WIN) rk[k] = atomicAdd(&cnt[w], 1u);
+            else { const u32 r = atomicAdd(&a.hist[lv[k] - L0 - 1u], 1u); if (SCATTER) rk[k] = r; }
+        }
+        __syncthreads();
+        if (cnt[t]) { const u32 r = atomicAdd(&a.hist[lo + t - L0 - 1u], cnt[t]); if (SCATTER) base_w[t] = r; }
+        if (SCATTER) {
+            __syncthreads();
+#pragma unroll
+            for (u32 k = 0; k < AGRP_PER; ++k) {
+                if (!id[k]) continue;
+                const u32 w = lv[k] - lo;
+                const u32 pos = w < AGRP_WIN ? base_w[w] + rk[k] : rk[k];
+                if (pos < d.fired_cap) d.fired[pos] = id[k] - 1u; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
             }
         }
+        __syncthreads();
     }
 }
 // hist[k] (EDTs of level L0 + 1 + k) -> start offsets in the fired log behind the seeds; level_start[] for every level of the run
@@ -1684,32 +1717,6 @@ __global__ __launch_bounds__(1024) void k_async_scan(Dev d, ADev a) {
         __syncthreads();
     }
     if (threadIdx.x == 0) { c->total_out = carry_s; c->n_lv_prev = n_lv; }
-}
-__global__ void k_async_scatter(Dev d, ADev a) {
-    const ACtl *c = a.c;
-    const u64 gs = (u64)gridDim.x * blockDim.x, t0 = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    for (u32 s = 0; s < ANSH; ++s) {
-        const u32 n = c->sh[s].tail < a.cap ? c->sh[s].tail : a.cap;
-        for (u64 i0 = (t0 & ~63ull); i0 < n; i0 += gs) {
-            const u64 i = i0 + (t0 & 63u);
-            const u64 v = i < n ? a.q[(size_t)s * a.cap + i] : 0ull;
-            const u32 id = (u32)v, lv = (u32)(v >> 32);
-            const bool mine = id != 0 && !(id & A_EVT) && lv > c->L0 && lv < d.max_levels;
-            u32 pos = 0;
-            u64 todo = __ballot(mine);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const u32 l0 = __shfl(lv, leader);
-                const u64 grp = __ballot(mine && lv == l0) & todo;
-                u32 base = 0;
-                if ((int)lane_id() == leader) base = atomicAdd(&a.hist[l0 - c->L0 - 1u], (u32)__popcll(grp));
-                base = __shfl(base, leader);
-                if (mine && lv == l0) pos = base + rank_in(grp);
-                todo &= ~grp;
-            }
-            if (mine) { if (pos < d.fired_cap) d.fired[pos] = id - 1u; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); }
-        }
-    }
 }
 // fold the run back into the between-runs view (what k_end does for a level-synchronous run); latch counters go back to their records
 __global__ void k_async_end(Dev d, ADev a, u32 K) {
@@ -3369,15 +3376,28 @@ static int run_async(ocrgpu_engine *e) {
     Dev &d = e->d;
     ADev a = e->ad; a.n_evt = e->n_evt;
     const bool timing = e->have_events;
-    k_async_reset<<<1024, 256, 0, e->stream>>>(a);
-    k_async_init<<<1, 64, 0, e->stream>>>(d, a);
-    k_async_seed<<<256, 256, 0, e->stream>>>(d, a);
+#ifdef OCRGPU_ASTAMPS
+    static double hacc[8]; static u64 hn; int hk = 0;
+    auto hnow = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double ht = hnow();
+#define HSTAMP() { double t2 = hnow(); hacc[hk++] += t2 - ht; ht = t2; }
+#else
+#define HSTAMP()
+#endif
+    k_async_reset<<<1024, 256, 0, e->stream>>>(a); HSTAMP();
+    k_async_init<<<1, 64, 0, e->stream>>>(d, a); HSTAMP();
+    k_async_seed<<<256, 256, 0, e->stream>>>(d, a); HSTAMP();
     if (timing) HIPCHK(hipEventRecord(e->ev0, e->stream));
-    k_async<<<e->async_waves, 64, 0, e->stream>>>(d, a);
+    HSTAMP();
+    k_async<<<e->async_waves, 64, 0, e->stream>>>(d, a); HSTAMP();
     if (timing) HIPCHK(hipEventRecord(e->ev1, e->stream));
-    k_async_hist<<<1024, 256, 0, e->stream>>>(d, a);
+    HSTAMP();
+#ifdef OCRGPU_ASTAMPS
+    if ((++hn & 7) == 0) fprintf(stderr, "[run_async host us per call] reset %.1f init %.1f seed %.1f ev0 %.1f k_async %.1f ev1 %.1f\n", hacc[0] / hn, hacc[1] / hn, hacc[2] / hn, hacc[3] / hn, hacc[4] / hn, hacc[5] / hn);
+#endif
+    k_async_group<false><<<2048, 256, 0, e->stream>>>(d, a);
     k_async_scan<<<1, 1024, 0, e->stream>>>(d, a);
-    k_async_scatter<<<1024, 256, 0, e->stream>>>(d, a);
+    k_async_group<true><<<2048, 256, 0, e->stream>>>(d, a);
     if (e->launch_index > 0xFFFF0000u) e->launch_index = 8;
     const u32 K = ++e->launch_index;
     k_async_end<<<64, 256, 0, e->stream>>>(d, a, K);
@@ -3395,11 +3415,15 @@ extern "C" int ocrgpu_resolve(ocrgpu_engine_t *e, u64 max_levels, ocrgpu_stats_t
     bool done = false;
     if (e->async_mode && !max_levels && e->d.n_loc <= 1 && !e->defer_drain) {
         // apply what the main program queued (EVENTS phases only: nothing fires), then look at what is ready and at what the DAG is made of
-        r = run_steps(e, 0u, ~0ull, false);
-        if (r) return r;
-        k_report<<<1, 64, 0, e->stream>>>(e->d, 0u, RP_QUEUE | RP_REND | RP_ASYNC | RP_ERR, e->pinned_dev);
-        HIPCHK(hipStreamSynchronize(e->stream));
+        // (the satisfy calls drain their own records unless told otherwise, so as a rule the first look finds the queue empty)
+        r = seal(e); if (r) return r;
         const u32 *pn = e->pinned_done;
+        for (int look = 0; look < 2; ++look) {
+            k_report<<<1, 64, 0, e->stream>>>(e->d, 0u, RP_QUEUE | RP_REND | RP_ASYNC | RP_ERR, e->pinned_dev);
+            HIPCHK(hipStreamSynchronize(e->stream));
+            if (look || pn[33009] <= pn[33008]) break;
+            r = run_steps(e, 0u, ~0ull, false); if (r) return r;
+        }
         const u32 seeds = pn[33011] - pn[33010];
         const bool clean = pn[33040] == 0 && pn[33009] <= pn[33008] && pn[33043] <= pn[33042] && pn[33044] + 2u < e->d.max_levels;
         if (clean && seeds && pn[33041] <= AMAX_ROW && (e->async_mode >= 2 || seeds <= AMAX_SEEDS)) { r = run_async(e); if (r) return r; done = true; }

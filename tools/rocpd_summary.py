@@ -47,7 +47,7 @@ def main():
     lines = ["source: ocr_amd/csrc/ocrgpu.hip sha256[:16]=" + kernel_source_hash()]
     bench = json.loads(open(os.path.join(src, "trace.json")).read().strip().splitlines()[-1])
     lines.append("bench line of the traced run: " + json.dumps({k: bench[k] for k in ("value", "ms_per_step", "steps", "warmup")}))
-    for n, c, t, a, mn, mx in rows[:3]:
+    for n, c, t, a, mn, mx in rows[:6]:
         lines.append(f"kernel-trace: {n}: {c} launches, avg {a / 1000:.3f} us, min {mn / 1000:.3f}, max {mx / 1000:.3f}, total {t / 1e6:.3f} ms")
     for sub in ("pmc_fetch", "pmc_write", "pmc_atom"):
         p = os.path.join(src, sub, "pmc_results.db")
@@ -55,7 +55,7 @@ def main():
             continue
         per = pmc_per_kernel(p)
         for k, ctrs in per.items():
-            if "k_step" not in k:
+            if "k_step" not in k and "k_async(" not in k and not k.startswith("k_async"):
                 continue
             for ctr, (n, s) in sorted(ctrs.items()):
                 lines.append(f"{sub}: {k}: {ctr} sum={s:.0f} over {n} dispatches (per dispatch {s / n:.1f})")
