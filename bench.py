@@ -312,19 +312,38 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     part = LayeredPartition(N, width, rank, world, device=local, flags=engine.F_TIMING, allreduce_sum=allreduce_sum)
     part.build()
     distributed_exchange(part, dist)             # deliver what construction sent across (nothing for this DAG)
-    # the per-level loop and the exchange run in C over libocrgpu's own RCCL communicator (ocrgpu_resolve_exchange); when
-    # RCCL cannot come up (a rehearsal with several ranks on one GPU) the same protocol runs from Python over gloo
-    # Transports, best first (OCRGPU_BENCH_TRANSPORT = windows | rccl | gloo picks one): peer windows (stores into the
-    # receiver's memory over xGMI, no collective), the RCCL all-to-all, records staged through the host over gloo.
-    want = os.environ.get("OCRGPU_BENCH_TRANSPORT", "auto")
-    transport = "gloo"
-    if want in ("auto", "windows") and windows_up(part, torch, dist, rank, world):
-        transport = "windows"
-    elif want in ("auto", "rccl") and backend == "nccl" and c_transport_up(part, torch, dist, rank, world):
-        transport = "rccl"
+    # the per-level loop and the exchange run in C (ocrgpu_resolve_exchange) over peer windows or libocrgpu's own RCCL communicator;
+    # when neither comes up (a rehearsal with several ranks on one GPU has no RCCL) the same protocol runs from Python over gloo
     part.eng.snapshot()
     part.eng.sync()
     expect_levels = N // width + 1
+
+    # ---- what a resolve must leave behind: the order-independent digest over (EDT id, level, HASH value) of the WHOLE DAG, from
+    # a single-partition resolve of the same global DAG on rank 0's GPU (the engine whose N = 1 record bench.py holds to the CPU
+    # restatement bit by bit).  Every rank folds its own EDTs on the device (ocrgpu_digest_edts), the sums are added up over
+    # gloo, and the total must be this number: records that crossed partitions arrived with their payloads, not just in the right
+    # count (hc-dist-policy.c:2208).  Checked in the untimed proof resolve and again after the timed loop.
+    want_digest = [None]
+    if rank == 0:
+        whole = LayeredPartition(N, width, 0, 1, device=local)
+        whole.build()
+        whole.satisfy_start()
+        wst = whole.eng.resolve()
+        assert wst.fired == N + 1 and sum(wst.err) == 0, (wst.fired, list(wst.err))
+        whole.check()
+        want_digest = [whole.eng.digest_edts(0, whole.n_local_edts)]
+        whole.eng.close()
+        del whole
+    dist.broadcast_object_list(want_digest, src=0)
+    want_digest = int(want_digest[0])
+
+    def global_digest():
+        mine = part.eng.digest_edts(0, part.n_local_edts)
+        if transport in os.environ.get("OCRGPU_BENCH_INJECT_DIGEST", "").split(",") and rank == world - 1:
+            mine ^= 1 << 17                      # (tests: one rank's record is off by one bit)
+        halves = torch.tensor([mine & 0xFFFFFFFF, mine >> 32], dtype=torch.int64)   # (two halves: no signed overflow in the reduction)
+        dist.all_reduce(halves, group=grp)
+        return (int(halves[0].item()) + (int(halves[1].item()) << 32)) & 0xFFFFFFFFFFFFFFFF
 
     def step(time_steps=False):
         part.eng.restore()
@@ -333,27 +352,62 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
             return part.eng.resolve_exchange(no_cascade=True, time_steps=time_steps)
         return resolve_distributed(part, dist)
 
-    # one untimed resolve proves the transport on the real DAG before anything is timed; a transport that fails it on any
-    # rank (an exception, a wrong level count) is dropped by all ranks together and the next one takes over
-    while transport != "gloo":
+    # Transports, best first (OCRGPU_BENCH_TRANSPORT = windows | rccl | gloo picks where the chain starts): peer windows (stores
+    # into the receiver's memory over xGMI, no collective), the same windows with every wave releasing at system scope itself
+    # (OCRGPU_PEER_FENCE=wave), the RCCL all-to-all, records staged through the host over gloo.  One untimed resolve proves each
+    # candidate on the real DAG before anything is timed: a transport that fails it on any rank -- an exception, a wrong level
+    # count, a digest that is not the single-partition one -- is dropped by all ranks together and the next one takes over.
+    want = os.environ.get("OCRGPU_BENCH_TRANSPORT", "auto")
+    chain = {"auto": ["windows", "windows-wave-fence", "rccl", "gloo"], "windows": ["windows", "windows-wave-fence", "gloo"],
+             "rccl": ["rccl", "gloo"], "gloo": ["gloo"]}[want]
+
+    def bring_up(name):
+        if name.startswith("windows"):
+            if name == "windows-wave-fence":
+                os.environ["OCRGPU_PEER_FENCE"] = "wave"
+            else:
+                os.environ.pop("OCRGPU_PEER_FENCE", None)
+            return windows_up(part, torch, dist, rank, world)
+        if name == "rccl":
+            return backend == "nccl" and c_transport_up(part, torch, dist, rank, world)
+        return True
+
+    def take_down(name):
+        if name.startswith("windows"):
+            part.eng.peer_fini()
+        elif name == "rccl":
+            part.eng.comm_fini()
+        part.eng.restore()                        # the failed resolve's leftovers (records waiting in the send regions) do not
+        part.eng.exchange_reset()                 # reach the next candidate's self-test round
+        part.eng.sync()
+
+    transport, proof = None, ""
+    for name in chain:
+        if not bring_up(name):
+            continue
+        transport = name
         why = ""
         try:
-            if os.environ.get("OCRGPU_BENCH_INJECT_FAILURE") == transport and rank == world - 1:
+            if os.environ.get("OCRGPU_BENCH_INJECT_FAILURE") == name and rank == world - 1:
                 raise RuntimeError("injected (tests: the other ranks must time out, and everybody falls back together)")
             got = step()
             assert got == expect_levels, f"{got} levels, expected {expect_levels}"
         except Exception as ex:  # noqa: BLE001
             why = f"{type(ex).__name__}: {str(ex)[:300]}"
-        if all_ok(torch, dist, not why):
-            break
-        print(f"[bench] rank {rank}: transport {transport} failed its first resolve ({why or 'on another rank'})", file=sys.stderr)
-        if transport == "windows":
-            part.eng.peer_fini()
-            transport = "rccl" if want == "auto" and backend == "nccl" and c_transport_up(part, torch, dist, rank, world) else "gloo"
-        else:
-            part.eng.comm_fini()
-            transport = "gloo"
+        if all_ok(torch, dist, not why):         # (everybody finished the resolve: the collective below cannot hang on a rank that threw)
+            got_digest = global_digest()
+            if got_digest == want_digest:
+                proof = f"digest {got_digest:016x} over (EDT id, level, HASH value) of all {N + 1} EDTs, summed over the ranks"
+                break
+            why = f"digest {got_digest:016x}, the single-partition resolve leaves {want_digest:016x}"
+        print(f"[bench] rank {rank}: transport {name} failed its first resolve ({why or 'on another rank'})", file=sys.stderr)
+        take_down(name)
+        transport = None
+    if transport is None:
+        raise SystemExit("bench.py: no transport passed its first resolve (the last one tried was gloo with host-staged records): PARITY FAILURE")
     backend = {"windows": "peer windows: records stored into the receiver's memory over xGMI, no collective; C loop ocrgpu_resolve_exchange",
+               "windows-wave-fence": "peer windows (OCRGPU_PEER_FENCE=wave: every wave releases at system scope): records stored into the "
+                                     "receiver's memory over xGMI, no collective; C loop ocrgpu_resolve_exchange",
                "rccl": "all-to-all (RCCL, C transport: ocrgpu_resolve_exchange)",
                "gloo": "all-to-all (gloo, host-staged records)"}[transport]
     build_s = time.time() - t0
@@ -378,6 +432,9 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     st = part.eng.stats()
     assert sum(st.err) == 0, list(st.err)
     part.check()                                 # every owned EDT fired at the level of its layer
+    got_digest = global_digest()                 # ... and the last timed resolve left the record the single-partition resolve leaves
+    if got_digest != want_digest:
+        raise SystemExit(f"PARITY FAILURE after the timed loop over {transport}: digest {got_digest:016x}, the single-partition resolve leaves {want_digest:016x}")
     fired = allreduce_sum(st.fired)
     edt_sat = allreduce_sum(st.edt_sat)
     assert fired == N + 1, (fired, N + 1)
@@ -406,8 +463,8 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
                        "n_edt": N + 1, "n_satisfactions": n_sat, "levels": int(levels), "transport": transport,
                        "us_per_level": round(dt / args.steps / max(int(levels), 1) * 1e6, 1),
                        "edts_fired_per_s": (N + 1) / (dt / args.steps), "build_s": round(build_s, 2),
-                       "parity": "every EDT fired at the level of its layer on every rank; partition invariance vs the "
-                                 "single-partition oracle is proven by tests/test_gpu_partitioned.py and test_gpu_workload_partition.py"},
+                       "parity": f"{proof} = the digest a single-partition resolve of the same DAG leaves on rank 0's GPU (compared in the "
+                                 f"untimed first resolve and again after the timed loop); every EDT fired at the level of its layer on every rank"},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / step_kernel_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                          "frac": alg_bytes / step_kernel_s / 1e9 / 8000.0, "traffic": None,
                          "kernel": kernel_note,

@@ -363,6 +363,22 @@ int ocrgpu_sync(ocrgpu_engine_t *e);
 /* ---- results (by engine index = creation order; use ocrgpu_guid_get to go from a guid) -------- */
 /* level_out[i] = level EDT first+i fired at (-1 never), val_out[i] = its HASH fold */
 int ocrgpu_read_edts(ocrgpu_engine_t *e, uint64_t first, uint64_t n, int32_t *level_out, uint64_t *val_out, int where);
+/* The same record folded on the device: *digest_out = sum modulo 2^64 over EDTs [first, first+n) of
+ * ocrgpu_digest_term(paramv[0], level, value) -- order-independent, so partitions of one DAG (whose EDTs carry a
+ * partition-independent paramv[0]) add their digests up and compare the total with a single-partition resolve of the same
+ * DAG.  What the comparison stands for: the satisfies that crossed partitions arrived with their payloads
+ * (PD_MSG_DEP_SATISFY carries the datablock, hc-dist-policy.c:2208), not merely in the right number.                     */
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint64_t ocrgpu_digest_term(uint64_t param0, int32_t level, uint64_t value) {
+    uint64_t z = param0 * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)level;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z ^= value;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+int ocrgpu_digest_edts(ocrgpu_engine_t *e, uint64_t first, uint64_t n, uint64_t *digest_out);
 /* OCREVS(code, aux) of explicit events (which = 0) or of the output events of EDTs first.. (which = 1) */
 int ocrgpu_read_events(ocrgpu_engine_t *e, int which, uint64_t first, uint64_t n, uint64_t *state_out, int where);
 /* values of explicit DBs (which = 0) or of the output DBs of EDTs first.. (which = 1; 0 if not created) */

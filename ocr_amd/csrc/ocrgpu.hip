@@ -2255,8 +2255,10 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
         if (cnt > stride - 1) cnt = stride - 1;
         for (u64 k = part * (u64)blockDim.x + threadIdx.x; k < cnt; k += per * (u64)blockDim.x) apply_record(d, recs[(u64)s * stride + k], db_floor);
     }
-    // (every wave waits for its own stores, the barrier joins them, ONE lane releases for the workgroup at device scope: a release is
-    // cumulative over what happens before it, and a fence per wave -- each a write-back of the L2 -- was most of this kernel's tail)
+    // (every wave waits for its own stores -- the explicit s_waitcnt: a workgroup-scope release compiles to no vector-memory wait on
+    // this target -- the barrier joins them, ONE lane releases for the workgroup at device scope: a release is cumulative over what
+    // happens before it, and a fence per wave -- each a write-back of the L2 -- was most of this kernel's tail)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) { __threadfence(); last = atomicAdd(&words[1025], 1u) == gridDim.x - 1 ? 1u : 0u; if (last) { words[1025] = 0; __threadfence(); } }
@@ -2303,7 +2305,7 @@ __host__ __device__ __forceinline__ size_t peer_regions_off(u32 n_loc) { return 
 __device__ __forceinline__ SendRec *peer_region(char *base, u32 n_loc, u64 cap, u32 parity, u32 src) {
     return (SendRec *)(base + peer_regions_off(n_loc)) + ((size_t)parity * n_loc + src) * cap;
 }
-__global__ void k_peer_push(Dev d, PeerDev pd, u64 round, u32 K, u32 end) {
+__global__ void k_peer_push(Dev d, PeerDev pd, u64 round, u32 K, u32 end, u32 wave_fence) {
     const u32 per_dest = peer_push_blocks(d.n_loc);
     const u32 p = blockIdx.x / per_dest, part = blockIdx.x % per_dest;
     if (end && blockIdx.x == 0 && threadIdx.x == 0) end_of_run(d, K); // (k_end rides along: it changes nothing that is read here)
@@ -2319,8 +2321,14 @@ __global__ void k_peer_push(Dev d, PeerDev pd, u64 round, u32 K, u32 end) {
     // Every workgroup releases its stores at SYSTEM scope before it is counted (fence - atomic - atomic - fence: the last workgroup's
     // fence in front of the arrival word then orders everybody's records before it, for an observer on another GPU too).  Such a
     // fence writes the L2 back each time, which is why a destination gets few workgroups when there are many destinations, and why
-    // ONE lane issues it for the workgroup: the waves wait for their own stores (workgroup scope), the barrier joins them, and a
-    // release is cumulative over everything that happens before it.
+    // ONE lane issues it for the workgroup.  That lane's fence waits for ITS wave's stores only, and a workgroup-scope release
+    // compiles to no wait at all on this target (the waves of a workgroup share one vector L1), so every wave first waits until
+    // its own stores have been acknowledged by the L2 -- the explicit s_waitcnt below -- and only then joins the barrier: when
+    // lane 0 writes the L2 back, all 256 lanes' records are in it.
+    // OCRGPU_PEER_FENCE=wave: every wave releases at system scope itself (the conservative form, for a machine on which the
+    // shared release turns out not to be enough between two devices).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave_fence) __threadfence_system();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) __threadfence_system();
@@ -2664,7 +2672,7 @@ struct ocrgpu_engine {
     void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records;
     // peer windows (ocrgpu_peer_*): my window, the device table of everybody's, what was opened from other processes, the round
     // counter every partition advances together, the wait limit in wall-clock ticks; hdr_fresh: the step just queued wrote the headers
-    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; bool peer_on, hdr_fresh, ahead_timed, end_pending; hipEvent_t ra_ev[2];
+    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; u32 peer_fence_wave; bool peer_on, hdr_fresh, ahead_timed, end_pending; hipEvent_t ra_ev[2];
     u64 *wp; u64 wp_cap, wp_head, wp_tail; // workpile: ring of guids in HBM, indices kept by the (single) caller side
     // reclaimed capacity (ocrgpu_reclaim, ocrgpu_db_destroy): device tables, host mirrors of the free-stack heights and of the
     // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
@@ -2770,7 +2778,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     ocrgpu_engine *e = new ocrgpu_engine();
     e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
     e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0;
-    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false; e->ra_ev[0] = e->ra_ev[1] = nullptr;
+    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_fence_wave = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false; e->ra_ev[0] = e->ra_ev[1] = nullptr;
     e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
     memset(&e->rc, 0, sizeof e->rc); e->n_free_edt = e->n_free_evt = e->n_free_db = e->n_held = 0; e->mut_epoch = 0; e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
@@ -3814,6 +3822,8 @@ extern "C" int ocrgpu_peer_connect(ocrgpu_engine_t *e, const void *handles) {
     HIPCHK(hipStreamSynchronize(e->stream));
     const char *ms = getenv("OCRGPU_PEER_TIMEOUT_MS");
     e->peer_limit = 100000ull * (u64)(ms && atoi(ms) > 0 ? atoi(ms) : 2000); // 100 MHz ticks
+    const char *pf = getenv("OCRGPU_PEER_FENCE");
+    e->peer_fence_wave = pf && !strcmp(pf, "wave") ? 1u : 0u;
     e->peer_opened.swap(opened); e->peer_round = 0; e->peer_on = true;
     return 0;
 }
@@ -3835,7 +3845,7 @@ static int peer_exchange(ocrgpu_engine **g, u32 n, u64 *h, bool ahead = false, u
         HIPCHK(hipSetDevice(e->device));
         if (d.n_loc > 1024) FAIL(OCRGPU_EINVAL, "more than 1024 locations");
         const PeerDev pd{e->peer_base_dev, e->peer_win, e->cfg.location, e->peer_cnt};
-        k_peer_push<<<d.n_loc * peer_push_blocks(d.n_loc), 256, 0, e->stream>>>(d, pd, e->peer_round, e->launch_index, e->end_pending ? 1u : 0u); // (the headers are made here)
+        k_peer_push<<<d.n_loc * peer_push_blocks(d.n_loc), 256, 0, e->stream>>>(d, pd, e->peer_round, e->launch_index, e->end_pending ? 1u : 0u, e->peer_fence_wave); // (the headers are made here)
         e->end_pending = false;
         HIPCHK(hipGetLastError());
     }
@@ -4084,6 +4094,10 @@ extern "C" int ocrgpu_workpile_push(ocrgpu_engine_t *e, u32 type, u64 n, const u
     }
     if (e->wp_tail - e->wp_head + n > e->wp_cap) FAIL(OCRGPU_ENOMEM, "workpile full (%llu entries; the reference's deque asserts here, deque.c:194)", (unsigned long long)e->wp_cap);
     const hipMemcpyKind kind = where == OCRGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    // the indices are positions modulo wp_cap: an empty pile goes back to the middle of the index space, and a head that a
+    // PUSHBACK would take below zero moves up by one whole turn together with the tail (same slots, no wrap of the u64)
+    if (e->wp_tail == e->wp_head) e->wp_head = e->wp_tail = e->wp_cap;
+    if (type == OCRGPU_WP_PUSHBACK && e->wp_head < n) { e->wp_head += e->wp_cap; e->wp_tail += e->wp_cap; }
     u64 first = type == OCRGPU_WP_PUSH ? e->wp_tail : e->wp_head - n; // PUSHBACK of n guids: guids[0] ends up at the head
     for (u64 done = 0; done < n;) {
         const u64 pos = (first + done) % e->wp_cap, run = n - done < e->wp_cap - pos ? n - done : e->wp_cap - pos;
@@ -4212,6 +4226,32 @@ extern "C" int ocrgpu_read_edts(ocrgpu_engine_t *e, u64 first, u64 n, s32 *level
     k_levels<<<2048, 256, 0, e->stream>>>(e->d, first, n, dl);
     if (dv) k_read_vals<<<nblk(n), 256, 0, e->stream>>>(e->d, first, n, dl, dv);
     if ((r = stage_out_copy(e, level_out, dl, n, where)) || (r = stage_out_copy(e, val_out, dv, n, where))) return r;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+__global__ void k_digest_edts(Dev d, u64 first, u64 n, const s32 *level, const u64 *val, u64 *out) {
+    u64 acc = 0;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        acc += ocrgpu_digest_term(d.edt[first + i].param0, level[i], val[i]);
+    for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+    if (lane_id() == 0 && acc) atomicAdd((unsigned long long *)out, (unsigned long long)acc);
+}
+extern "C" int ocrgpu_digest_edts(ocrgpu_engine_t *e, u64 first, u64 n, u64 *digest_out) {
+    ENTER(e);
+    if (!digest_out) FAIL(OCRGPU_EINVAL, "null argument");
+    *digest_out = 0;
+    if (n == 0) return 0;
+    if (first + n > e->n_edt) FAIL(OCRGPU_EINVAL, "EDT range [%llu,%llu) beyond %u created", (unsigned long long)first, (unsigned long long)(first + n), e->n_edt);
+    int r = stage_reserve(e, rup(4 * n) + rup(8 * n) + 256); if (r) return r;
+    s32 *dl = (s32 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += rup(4 * n);
+    u64 *dv = (u64 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += rup(8 * n);
+    u64 *dd = (u64 *)(e->stage_dev + e->stage_dev_off); e->stage_dev_off += 256;
+    HIPCHK(hipMemsetAsync(dd, 0, 8, e->stream));
+    k_fill_i32<<<nblk(n), 256, 0, e->stream>>>(dl, n, -1);
+    k_levels<<<2048, 256, 0, e->stream>>>(e->d, first, n, dl);
+    k_read_vals<<<nblk(n), 256, 0, e->stream>>>(e->d, first, n, dl, dv);
+    k_digest_edts<<<2048, 256, 0, e->stream>>>(e->d, first, n, dl, dv, dd);
+    HIPCHK(hipMemcpyAsync(digest_out, dd, 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }

@@ -77,13 +77,23 @@ EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error
            "ocrgpu_comm_get_unique_id", "ocrgpu_comm_init", "ocrgpu_comm_fini", "ocrgpu_comm_alltoall", "ocrgpu_exchange",
            "ocrgpu_exchange_local", "ocrgpu_resolve_exchange", "ocrgpu_resolve_exchange_local", "ocrgpu_workpile_push",
            "ocrgpu_workpile_pop", "ocrgpu_db_destroy", "ocrgpu_reclaim", "ocrgpu_peer_export", "ocrgpu_peer_connect",
-           "ocrgpu_peer_fini"]
+           "ocrgpu_peer_fini", "ocrgpu_digest_edts"]
 PEER_HANDLE_BYTES = 128
 RX_NO_CASCADE = 1
 RX_TIME_STEPS = 2
 WP_PUSH, WP_PUSHBACK, WP_POP, WP_STEAL = 0, 1, 0, 1
 
 _lib = None
+
+
+def digest_term(param0, level, value):
+    """include/ocrgpu.h:ocrgpu_digest_term on numpy arrays (the host-side twin the tests hold the device fold against)"""
+    with np.errstate(over="ignore"):
+        z = np.asarray(param0, np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.asarray(level, np.int32).astype(np.uint32).astype(np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = z ^ np.asarray(value, np.uint64)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
 
 
 def load_library(path=_LIB_PATH):
@@ -400,6 +410,12 @@ class Engine:
         lv, val = np.empty(n, np.int32), np.empty(n, np.uint64)
         self._chk(self.lib.ocrgpu_read_edts(self.h, C.c_uint64(first), C.c_uint64(n), _ptr(lv), _ptr(val), HOST))
         return lv, val
+
+    def digest_edts(self, first, n):
+        """sum modulo 2^64 of ocrgpu_digest_term(paramv[0], level, value) over EDTs [first, first+n), folded on the device"""
+        out = C.c_uint64()
+        self._chk(self.lib.ocrgpu_digest_edts(self.h, C.c_uint64(first), C.c_uint64(n), C.byref(out)))
+        return out.value
 
     def read_events(self, which, first, n):
         out = np.empty(n, np.uint64)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_header_and_library_agree():
     hdr = open(os.path.join(ROOT, "include", "ocrgpu.h")).read()
     declared = set(re.findall(r"\b(ocrgpu_[a-z_0-9]+)\s*\(", hdr))
-    declared -= {"ocrgpu_engine", "ocrgpu_engine_t", "ocrgpu_reclaim_t"}
+    declared -= {"ocrgpu_engine", "ocrgpu_engine_t", "ocrgpu_reclaim_t", "ocrgpu_digest_term"}   # (types; a static inline of the header)
     assert declared == set(engine.EXPORTS)
     lib = engine.load_library()
     for name in declared:

@@ -140,3 +140,22 @@ def test_values_travel_between_waves():
     s = b.finish(second, start=start)
     r, st, _, _ = _run(s, 0)
     assert st.async_runs == 1 and r.diff(O.run_restatement(s)) == []
+
+
+def test_device_digest_is_the_fold_of_the_record():
+    """ocrgpu_digest_edts = sum modulo 2^64 of ocrgpu_digest_term(paramv[0], level, value) over the EDTs, whichever worker loop ran"""
+    s = ALL["layered_100k"]
+    want = None
+    for flags in (0, engine.F_NO_ASYNC):
+        p = engine.StreamProgram(s, flags=flags).build()
+        p.resolve()
+        lv, val = p.eng.read_edts(0, s.n_edt)
+        ids = np.arange(s.n_edt, dtype=np.uint64)       # StreamProgram gives every EDT its stream index as paramv[0]
+        with np.errstate(over="ignore"):
+            host = int(engine.digest_term(ids, lv, val).sum(dtype=np.uint64))
+        assert p.eng.digest_edts(0, s.n_edt) == host
+        assert p.eng.digest_edts(5, 1000) == int(engine.digest_term(ids[5:1005], lv[5:1005], val[5:1005]).sum(dtype=np.uint64))
+        assert p.eng.digest_edts(0, 0) == 0
+        want = want or host
+        assert host == want
+        p.eng.close()

@@ -133,4 +133,13 @@ def test_workpile_push_pop_steal():
     assert ei.value.code == -12
     out = eng.workpile_pop(2000, steal=True)
     assert list(out) == list(range(501, 1041)) + list(range(5000, 5500))
+    # PUSHBACK moves the head down and POP the tail: with the pile never empty both indices walk down one step per round, past
+    # zero after capacity rounds -- the pile must keep working as a deque through that (the indices are positions modulo capacity)
+    eng.workpile_push(np.array([7, 8], np.uint64))
+    expect = [7, 8]
+    for k in range(2 * (16 + 1024) + 50):
+        eng.workpile_push(np.array([10_000 + k], np.uint64), back=True)
+        expect.insert(0, 10_000 + k)
+        assert list(eng.workpile_pop(1)) == [expect.pop()], k
+    assert list(eng.workpile_pop(10, steal=True)) == expect
     eng.close()

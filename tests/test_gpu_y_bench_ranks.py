@@ -46,8 +46,9 @@ def test_bench_two_ranks_on_one_gpu(backend, launcher, transport):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["config"]["n_edt"] == 2 * 400000 + 1 and 100 <= out["config"]["levels"] <= 103   # 100 layers + latch/sink
     wl = out["config"]["workload"]
+    assert "digest" in out["config"]["parity"]
     if transport == "auto":
-        assert "peer windows" in wl
+        assert "peer windows" in wl and out["config"]["transport"] == "windows"
     else:
         assert "all-to-all (gloo" in wl                          # one GPU: RCCL refuses two ranks on one device
     assert out["roofline"]["frac"] > 0
@@ -62,7 +63,32 @@ def test_bench_falls_back_when_the_windows_fail_mid_run():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert "all-to-all (gloo" in out["config"]["workload"] and "failed its first resolve" in r.stderr
+    # the next transport of the chain: the same windows with every wave releasing at system scope (OCRGPU_PEER_FENCE=wave)
+    assert out["config"]["transport"] == "windows-wave-fence" and "failed its first resolve" in r.stderr
+    assert "digest" in out["config"]["parity"]
+
+
+@pytest.mark.parametrize("bad,then", [("windows", "windows-wave-fence"), ("windows,windows-wave-fence", "gloo")])
+def test_bench_drops_a_transport_whose_digest_is_wrong(bad, then):
+    """one rank's digest over (EDT id, level, HASH value) is off by one bit after the proof resolve over `bad`: every rank drops that
+    transport (counts and levels were right -- only the record differs) and the run completes over the next one whose digest matches
+    the single-partition resolve of the same DAG"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(OCRGPU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OCRGPU_BENCH_INJECT_DIGEST=bad)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n-edt", "200000", "--width", "4000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["config"]["transport"] == then and "the single-partition resolve leaves" in r.stderr
+    assert "digest" in out["config"]["parity"]
+
+
+def test_bench_fails_when_no_transport_leaves_the_right_record():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(OCRGPU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OCRGPU_BENCH_INJECT_DIGEST="gloo", OCRGPU_BENCH_TRANSPORT="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n-edt", "200000", "--width", "4000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "PARITY FAILURE" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
