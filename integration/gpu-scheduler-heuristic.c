@@ -104,6 +104,7 @@ static u8 gpuSchedulerHeuristicGetWorkInvoke(ocrSchedulerHeuristic_t *self, ocrS
     int rc = ocrgpu_workpile_pop(ocrgpuBinding.engine, OCRGPU_WP_POP, 1, &g, &n, OCRGPU_HOST);
     OCRGPU_LEAVE();
     if(rc != OCRGPU_OK) return ocrgpuToOcrError(rc);
+    if(n == 1) OCRGPU_COUNT(nPopped);
     if(n == 1) { /* the worker dereferences the task at once (hc-worker.c:97-141): resolve its metadata here, as localDeguidify does */
         ocrPolicyDomain_t *pd = self->scheduler->pd;
         ocrFatGuid_t edt;
@@ -125,6 +126,7 @@ static u8 gpuSchedulerHeuristicNotifyInvoke(ocrSchedulerHeuristic_t *self, ocrSc
         OCRGPU_ENTER();
         int rc = ocrgpu_workpile_push(ocrgpuBinding.engine, OCRGPU_WP_PUSH, 1, &g, OCRGPU_HOST);
         OCRGPU_LEAVE();
+        OCRGPU_COUNT(nPushed);
         return ocrgpuToOcrError(rc);
     }
     case OCR_SCHED_NOTIFY_EDT_DONE: {

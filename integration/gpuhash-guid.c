@@ -16,6 +16,8 @@
 #include "ocr-config.h"
 #ifdef ENABLE_GUID_GPUHASH
 
+#include <stdio.h>
+#include <stdlib.h>
 #include "debug.h"
 #include "ocr-errors.h"
 #include "ocr-guid.h"
@@ -25,7 +27,7 @@
 
 #define DEBUG_TYPE GUID
 
-ocrgpuBinding_t ocrgpuBinding = {NULL, INIT_LOCK, 0, 1};
+ocrgpuBinding_t ocrgpuBinding = {NULL, INIT_LOCK, 0, 1, 0, 0, 0, 0, 0};
 
 typedef struct {
     ocrGuidProvider_t base;
@@ -57,6 +59,10 @@ static u8 gpuHashSwitchRunlevel(ocrGuidProvider_t *self, ocrPolicyDomain_t *PD, 
         break;
     case RL_MEMORY_OK:
         if((properties & RL_TEAR_DOWN) && RL_IS_LAST_PHASE_DOWN(PD, RL_MEMORY_OK, phase) && ocrgpuBinding.engine) {
+            if(getenv("OCRGPU_BINDING_STATS"))
+                fprintf(stderr, "GPUHASH binding: %llu guids made, %llu lookups, %llu released; GPU work-list: %llu pushed, %llu popped\n",
+                        (unsigned long long)ocrgpuBinding.nGuids, (unsigned long long)ocrgpuBinding.nLookups, (unsigned long long)ocrgpuBinding.nReleased,
+                        (unsigned long long)ocrgpuBinding.nPushed, (unsigned long long)ocrgpuBinding.nPopped);
             toReturn = ocrgpuToOcrError(ocrgpu_fini(ocrgpuBinding.engine));
             ocrgpuBinding.engine = NULL;
         }
@@ -111,6 +117,7 @@ static u8 gpuHashGetGuid(ocrGuidProvider_t *self, ocrGuid_t *guid, u64 val, ocrG
     u64 g = 0;
     u8 rc = GPUHASH_CALL(ocrgpu_guid_reserve(ocrgpuBinding.engine, (u32)kind, 1, &g, OCRGPU_HOST));
     if(rc) return rc;
+    OCRGPU_COUNT(nGuids);
     guid->guid = g;
     if(properties & GUID_PROP_TORECORD)
         rc = GPUHASH_CALL(ocrgpu_guid_put(ocrgpuBinding.engine, 1, &g, &val, OCRGPU_HOST));
@@ -155,6 +162,7 @@ static u8 gpuHashCreateGuid(ocrGuidProvider_t *self, ocrFatGuid_t *fguid, u64 si
 static u8 gpuHashGetVal(ocrGuidProvider_t *self, ocrGuid_t guid, u64 *val, ocrGuidKind *kind, u32 mode, MdProxy_t **proxy) {
     u64 g = OCRGPU_KEY(guid), v = 0;
     u8 rc = GPUHASH_CALL(ocrgpu_guid_get(ocrgpuBinding.engine, 1, &g, &v, OCRGPU_HOST));
+    OCRGPU_COUNT(nLookups);
     *val = v;                                   /* 0 when the guid does not resolve, as the reference's NULL entry */
     if(kind) *kind = (ocrGuidKind)OCRGPU_GUID_KIND(g);
     if(proxy) *proxy = NULL;                    /* remote metadata is not cloned by this provider */
@@ -188,6 +196,7 @@ static u8 gpuHashUnregisterGuid(ocrGuidProvider_t *self, ocrGuid_t guid, u64 **v
 static u8 gpuHashReleaseGuid(ocrGuidProvider_t *self, ocrFatGuid_t fguid, bool releaseVal) {
     u64 g = OCRGPU_KEY(fguid.guid);
     u8 rc = GPUHASH_CALL(ocrgpu_guid_remove(ocrgpuBinding.engine, 1, &g, OCRGPU_HOST));
+    OCRGPU_COUNT(nReleased);
     if(rc == 0 && releaseVal) {
         ASSERT(fguid.metaDataPtr != NULL);
         PD_MSG_STACK(msg);

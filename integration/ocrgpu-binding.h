@@ -27,12 +27,16 @@ typedef struct {
     ocrgpu_engine_t *engine;
     lock_t lock;              /* hal_lock: one caller at a time inside libocrgpu */
     u32 location, nLocations; /* this policy domain's LOCHOME id; how many partitions the comm-platform connects */
+    u64 nGuids, nLookups, nReleased, nPushed, nPopped; /* calls that reached the engine (updated under the lock); printed at
+                                                           tear-down when OCRGPU_BINDING_STATS is set: the evidence a test has
+                                                           that a run really went through these factories */
 } ocrgpuBinding_t;
 
 extern ocrgpuBinding_t ocrgpuBinding;
 
 #define OCRGPU_ENTER() hal_lock(&ocrgpuBinding.lock)
 #define OCRGPU_LEAVE() hal_unlock(&ocrgpuBinding.lock)
+#define OCRGPU_COUNT(field) __sync_fetch_and_add(&ocrgpuBinding.field, 1)
 /* libocrgpu's negative codes -> the reference's u8 convention (0 ok, OCR_E* from ocr/inc/ocr-errors.h) */
 static inline u8 ocrgpuToOcrError(int rc) {
     switch(rc) {

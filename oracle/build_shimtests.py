@@ -101,8 +101,37 @@ def build_perf():
     return built
 
 
+OUT_MI355X = os.path.join(HERE, "_ref", "mi355xtests")
+
+
+def build_mi355x():
+    """The same programs against the reference runtime BOOTED ON THE GPU FACTORIES (oracle/Makefile.mi355x ->
+    oracle/_ref/libocr_x86-mi355x.a: the reference's sources + integration/*.c, cfg names GPUHASH / GPU / GPU), into
+    oracle/_ref/mi355xtests/ with the machine configs beside them; tests/test_gpu_reference_boot.py runs them on the MI355X and
+    expects what tests/golden/reference_programs.json recorded from the stock runtime."""
+    from oracle import mkcfg
+    os.makedirs(OUT_MI355X, exist_ok=True)
+    for w in (1, 4):
+        open(os.path.join(OUT_MI355X, f"gpu-{w}w.cfg"), "w").write(mkcfg.cfg(w, guid="GPUHASH", heuristic="GPU", workpile="GPU"))
+    subprocess.check_call(["make", "-s", "-j8", "-f", "Makefile.mi355x"], cwd=HERE)
+    libdir = os.path.join(HERE, "_ref", "mi355x")     # the runtime as one shared object: the programs stay a few KB each
+    n = 0
+    for src in sources():
+        name = os.path.splitext(os.path.basename(src))[0]
+        cmd = ["gcc", "-O1", "-w", "-std=gnu11"] + APP_DEFS + ["-I", os.path.join(REF, "inc"), "-I", os.path.join(REF, "build", "x86"),
+               src, "-L", libdir, "-locr_x86-mi355x", "-Wl,-rpath,$ORIGIN/../mi355x", "-Wl,-rpath-link," + os.path.join(ROOT, "ocr_amd"),
+               "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread", "-lm", "-s", "-o", os.path.join(OUT_MI355X, name)]
+        n += subprocess.run(cmd, capture_output=True, text=True).returncode == 0
+    print(f"{n} of {len(sources())} programs built against libocr_x86-mi355x.so -> {OUT_MI355X}")
+    return n
+
+
 def main():
     sys.path.insert(0, ROOT)
+    if "--mi355x" in sys.argv:
+        from ocr_amd import build as B
+        B.build_lib()
+        return build_mi355x()
     from ocr_amd import build as B
     B.build_lib()
     B.build_shim()

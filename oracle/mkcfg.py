@@ -6,7 +6,8 @@ ocr/src/machine-description/ocr-machine-description.c:593-1140).  The reference'
 (ocr/scripts/Configs/config-generator.py) is Python 2 and is not run."""
 import sys
 
-def cfg(workers: int, guid: str = "COUNTED_MAP", db: str = "Regular", alloc_mb: int = 64) -> str:
+def cfg(workers: int, guid: str = "COUNTED_MAP", db: str = "Regular", alloc_mb: int = 64, heuristic: str = "HC", workpile: str = "HC") -> str:
+    """heuristic / workpile = "GPU" and guid = "GPUHASH" name the factories of integration/ (oracle/Makefile.mi355x builds)"""
     w = workers - 1
     rng = f"0-{w}"
     size = alloc_mb << 20
@@ -29,15 +30,15 @@ def cfg(workers: int, guid: str = "COUNTED_MAP", db: str = "Regular", alloc_mb: 
     sec("WorkerType0", name="HC"); sec("WorkerInst0", id=0, type="HC", workertype="master", comptarget=0)
     if workers > 1:
         sec("WorkerInst1", id=f"1-{w}", type="HC", workertype="slave", comptarget=f"1-{w}")
-    sec("WorkPileType0", name="HC"); sec("WorkPileInst0", id=rng, type="HC", dequetype="WORK_STEALING_DEQUE")
+    sec("WorkPileType0", name=workpile); sec("WorkPileInst0", id=rng, type=workpile, dequetype="WORK_STEALING_DEQUE")
     names = ["NULL", "WST", "DEQ", "LIST", "MAP", "PDSPACE", "DBSPACE", "DBTIME", "PR_WSH", "BIN_HEAP"]
     for i, n in enumerate(names):
         if n == "WST": sec(f"SchedulerObjectType{i}", name=n, kind="root")
         else: sec(f"SchedulerObjectType{i}", name=n)
     sec("SchedulerObjectInst0", id=0, type="WST")
-    for i, n in enumerate(["NULL", "HC", "ST", "PRIORITY", "STATIC"]):
+    for i, n in enumerate(["NULL", "HC", "ST", "PRIORITY", "STATIC"] + ([heuristic] if heuristic == "GPU" else [])):
         sec(f"SchedulerHeuristicType{i}", name=n)
-    sec("SchedulerHeuristicInst0", id=0, type="HC")
+    sec("SchedulerHeuristicInst0", id=0, type=heuristic)
     sec("SchedulerType0", name="COMMON")
     sec("SchedulerInst0", id=0, type="COMMON", workpile=rng, workeridfirst=0, schedulerObject=0,
         config="comp0:plc0:comm0", schedulerHeuristic=0)
@@ -45,4 +46,5 @@ def cfg(workers: int, guid: str = "COUNTED_MAP", db: str = "Regular", alloc_mb: 
 
 if __name__ == "__main__":
     workers = int(sys.argv[1]); guid = sys.argv[2] if len(sys.argv) > 2 else "COUNTED_MAP"
-    sys.stdout.write(cfg(workers, guid))
+    gpu = guid == "GPUHASH"
+    sys.stdout.write(cfg(workers, guid, heuristic="GPU" if gpu else "HC", workpile="GPU" if gpu else "HC"))
