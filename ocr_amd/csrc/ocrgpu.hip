@@ -206,9 +206,13 @@ __device__ __forceinline__ u32 ghash(const Dev &d, u64 g) { return (u32)((g * 0x
 // (removes give capacity back); a key already present gets the new value.  Concurrent puts of ONE key in one batch may
 // leave two entries (guids are unique; the reference's put does not check either): callers that race on a key use tryput.
 __device__ __forceinline__ void gtab_publish(const Dev &d, u64 h, u64 key, u64 val) {
-    d.gtab[h].y = val;
-    __threadfence();
-    atomicExch((unsigned long long *)&d.gtab[h].x, (unsigned long long)key);
+    // Value, then key, as two device-scope atomic exchanges on the two halves of ONE 16-byte slot: both are executed by the memory-side
+    // atomic unit of the slot's channel in the order this lane issued them, so whoever finds the key (tryput: with an atomic of its own)
+    // finds the value.  An agent-scope fence between a plain store and the exchange did the same job at the price of an L2 write-back
+    // and invalidate per wave and put (buffer_wbl2 sc1 / buffer_inv sc1 on gfx950): three of them per EDT made k_edt_create 3 ns per EDT.
+    __hip_atomic_exchange((unsigned long long *)&d.gtab[h].y, (unsigned long long)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // compiler order only (no instruction)
+    __hip_atomic_exchange((unsigned long long *)&d.gtab[h].x, (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ void gtab_put(const Dev &d, u64 key, u64 val) {
     for (int attempt = 0; attempt < 1024; ++attempt) { // a lost claim means another put made progress: walk the chain again
@@ -303,6 +307,26 @@ __device__ __forceinline__ u32 wave_append(u32 *tail, bool pred) {
         base = __shfl(base, leader);
     }
     return base + rank_in(m);
+}
+
+// workgroup-aggregated append: ONE atomic per workgroup (<= 1024 threads).  Every thread of the workgroup calls it (barriers inside);
+// lanes with pred get a unique index, the others an unspecified one.  Same-address device-scope atomics are served one after the
+// other (~30 ns each on gfx950, whoever issues them): a batch kernel that appends one entry per element to one list spends its time
+// there even with one atomic per wavefront (10.5M registrations = 164k wavefronts = 5 ms; k_reclaim_edts 50M lines = 24 ms).
+__device__ __forceinline__ u32 block_append(u32 *tail, bool pred, u32 *lds /* 18 words */) {
+    const u64 m = __ballot(pred);
+    const u32 w = threadIdx.x >> 6, nw = (blockDim.x + 63u) >> 6;
+    if (lane_id() == 0) lds[w] = (u32)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 t = 0;
+        for (u32 k = 0; k < nw; ++k) { const u32 c = lds[k]; lds[k] = t; t += c; }
+        lds[16] = t ? atomicAdd(tail, t) : 0u;
+    }
+    __syncthreads();
+    const u32 r = lds[16] + lds[w] + rank_in(m);
+    __syncthreads(); // lds may be reused by the next call
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1891,10 +1915,9 @@ __device__ __forceinline__ bool chan_register(const Dev &d, u32 x, u64 waiter, u
     return false;
 }
 
-// ocrAddDependence classification (hc-policy.c:2857-3074)
-__global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode, u32 nanny) {
-    u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// ocrAddDependence classification (hc-policy.c:2857-3074) of element i.  True: the dependence is a registration on a live event --
+// the caller appends {lx, lrec} to the registration log (k_add_dep does it with one atomic per workgroup).
+__device__ bool add_dep_one(const Dev &d, u64 i, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode, u32 nanny, u32 &lx, u64 &lrec) {
     u64 s = src[i];
     u32 didx, dslot, dflag;
     const u64 dg = dst[i];
@@ -1903,13 +1926,13 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
         // crosses as a SendRec; the owner resolves slot encoding and mode when it applies it
         const u32 dk = OCRGPU_GUID_KIND(dg);
         const bool r_edt = dk == OCRGPU_KIND_EDT;
-        if (!r_edt && !is_event_kind(dk)) { bad_op(d); return; }
+        if (!r_edt && !is_event_kind(dk)) { bad_op(d); return false; }
         const u32 xf = (r_edt && mode[i] == OCRMODE_NULL) ? XF_MODE_NULL : 0u;
-        if (s == OCRGPU_NULL_GUID) { emit_remote(d, dg, slot[i], xf, 0u); return; }
+        if (s == OCRGPU_NULL_GUID) { emit_remote(d, dg, slot[i], xf, 0u); return false; }
         u64 sv = gtab_get(d, s); u32 sk = OCRGPU_GUID_KIND(s);
-        if (!sv) { atomicAdd(&d.ctrl->err[is_event_kind(sk) ? ERR_LATE_WAITER : ERR_BAD_OP], 1u); return; }
-        if (sk == OCRGPU_KIND_DB) { emit_remote(d, dg, slot[i], xf, (u32)sv); return; }
-        if (!is_event_kind(sk)) { bad_op(d); return; }
+        if (!sv) { atomicAdd(&d.ctrl->err[is_event_kind(sk) ? ERR_LATE_WAITER : ERR_BAD_OP], 1u); return false; }
+        if (sk == OCRGPU_KIND_DB) { emit_remote(d, dg, slot[i], xf, (u32)sv); return false; }
+        if (!is_event_kind(sk)) { bad_op(d); return false; }
         u32 x = (u32)(sv - 1);
         const u32 sw = *evt_state(d, x);
         u32 st = sw & 0xFF;
@@ -1920,38 +1943,37 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
             atomicAdd((unsigned long long *)&d.counted[x], 1ull);
             emit_remote_raw(d, dg, slot[i], XF_LAZYREG, s, 0ull);
         }
-        if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); if (!lazy) counted_late_registration(d, x); emit_remote(d, dg, slot[i], xf, pv); return; }
-        if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }
+        if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); if (!lazy) counted_late_registration(d, x); emit_remote(d, dg, slot[i], xf, pv); return false; }
+        if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return false; }
         if (((sw >> 8) & 0xFF) == OCREVT_CHANNEL) { // the waiter in line is a remote destination
             u32 ri = atomicAdd(&d.ctrl->rdst_tail, 1u);
-            if (ri >= d.rdst_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+            if (ri >= d.rdst_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return false; }
             d.rdst[ri] = RemoteDst{dg, slot[i], xf};
             u32 pay;
             if (chan_register(d, x, ((u64)(RF_REMOTE << 28) << 32) | (u64)ri, pay)) emit_remote(d, dg, slot[i], xf, pay);
-            return;
+            return false;
         }
-        u32 ri = atomicAdd(&d.ctrl->rdst_tail, 1u), li = atomicAdd(&d.ctrl->log_tail, 1u);
-        if (ri >= d.rdst_cap || (u64)li + d.ctrl->chan_wait_used >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+        u32 ri = wave_append(&d.ctrl->rdst_tail, true);
+        if (ri >= d.rdst_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return false; }
         d.rdst[ri] = RemoteDst{dg, slot[i], xf};
-        d.log_src[li] = x;
-        d.log_rec[li] = ((u64)(RF_REMOTE << 28) << 32) | (u64)ri;
-        return;
+        lx = x; lrec = ((u64)(RF_REMOTE << 28) << 32) | (u64)ri;
+        return true;
     }
-    if (!resolve_dst(d, dg, slot[i], didx, dflag, dslot)) { bad_op(d); return; }
+    if (!resolve_dst(d, dg, slot[i], didx, dflag, dslot)) { bad_op(d); return false; }
     const bool d_edt = (dflag & RF_DST_EDT) != 0;
     u32 mnull = (d_edt && mode[i] == OCRMODE_NULL) ? RF_MODE_NULL : 0u;
     unsigned char *const acq_mode = d.ctrl->acq_mode;
     if (acq_mode && d_edt && s != OCRGPU_NULL_GUID) // registerSignalerTaskHc records the mode (hc-task.c:1373); a NULL source does not
         acq_mode[acq_index(d, didx, (dflag & RF_INLINE) ? 0u : INLINE_SLOTS + 1u, d.edt[didx].slot[0], dslot)] = (unsigned char)mode[i];
-    if (s == OCRGPU_NULL_GUID) { q_push(d, Rec{didx, 0u, dslot, dflag}); return; } // == satisfy(dst, slot, NULL)
+    if (s == OCRGPU_NULL_GUID) { q_push(d, Rec{didx, 0u, dslot, dflag}); return false; } // == satisfy(dst, slot, NULL)
     u64 sv = gtab_get(d, s);
     u32 sk = OCRGPU_GUID_KIND(s);
-    if (!sv) { atomicAdd(&d.ctrl->err[is_event_kind(sk) ? ERR_LATE_WAITER : ERR_BAD_OP], 1u); return; }
+    if (!sv) { atomicAdd(&d.ctrl->err[is_event_kind(sk) ? ERR_LATE_WAITER : ERR_BAD_OP], 1u); return false; }
     if (sk == OCRGPU_KIND_DB) { // mode recorded, then satisfy
         if ((u32)sv - 1 >= d.max_db && !(d.edt[(u32)sv - 1 - d.max_db].body & BODY_VAL_DONE)) atomicAdd(&d.ctrl->async_block, 1u); // the output datablock of an EDT that may never run: k_async would wait for its value
-        q_push(d, Rec{didx, (u32)sv, dslot, dflag | mnull}); return;
+        q_push(d, Rec{didx, (u32)sv, dslot, dflag | mnull}); return false;
     }
-    if (!is_event_kind(sk)) { bad_op(d); return; }
+    if (!is_event_kind(sk)) { bad_op(d); return false; }
     u32 x = (u32)(sv - 1);
     const u32 sw = *evt_state(d, x);
     u32 st = sw & 0xFF;
@@ -1972,13 +1994,13 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
             atomicAdd((unsigned long long *)&d.counted[x], 1ull);
         }
     }
-    if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); if (!lazy) counted_late_registration(d, x); q_push(d, Rec{didx, pv, dslot, dflag | mnull}); return; } // registerWaiterEventHcPersist :1143-1155
-    if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return; }    // registerWaiterEventHc :1078-1083
+    if (st == ST_SAT) { const u32 pv = (u32)*evt_val(d, x); if (!lazy) counted_late_registration(d, x); q_push(d, Rec{didx, pv, dslot, dflag | mnull}); return false; } // registerWaiterEventHcPersist :1143-1155
+    if (st != ST_LIVE) { atomicAdd(&d.ctrl->err[ERR_LATE_WAITER], 1u); return false; }    // registerWaiterEventHc :1078-1083
     if (((sw >> 8) & 0xFF) == OCREVT_CHANNEL) {
         const u32 dl = (!d_edt && OCRGPU_GUID_KIND(dst[i]) == OCRGPU_KIND_EVT_LATCH) ? RF_DST_LATCH : 0u;
         u32 pay;
         if (chan_register(d, x, ((u64)(((dflag | mnull | dl) << 28) | dslot) << 32) | (u64)didx, pay)) q_push(d, Rec{didx, pay, dslot, dflag | mnull});
-        return;
+        return false;
     }
     // Payload pre-resolution: when what this dependence will deliver is already known -- nothing (DB_MODE_NULL),
     // or the output DB / NULL_GUID of a built-in HASH / NOP body behind an output event -- write the pre-slot word
@@ -1998,13 +2020,22 @@ __global__ void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u3
         // line, in front of its wave's atomics -- 2.7 % of config 2's edges cost 4 % of a level that way)
         if (known) { pre = RF_PREFILLED; *((dflag & RF_INLINE) ? &d.edt[didx].slot[dslot] : &d.slots[(size_t)d.edt[didx].slot[0] + dslot]) = word; }
     }
-    u32 li = atomicAdd(&d.ctrl->log_tail, 1u);
-    if ((u64)li + d.ctrl->chan_wait_used >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // waiters[] top end = CHANNEL rings
-    d.log_src[li] = x;
     u32 dlatch = (!d_edt && OCRGPU_GUID_KIND(dst[i]) == OCRGPU_KIND_EVT_LATCH) ? RF_DST_LATCH : 0u;
     // k_async takes EDT pre-slots whose payload word is already there and LATCH DECR slots (order-free); anything else is counted
     if (d_edt ? !pre : (!dlatch || dslot != OCRLATCH_DECR)) atomicAdd(&d.ctrl->async_block, 1u);
-    d.log_rec[li] = ((u64)(((dflag | mnull | pre | dlatch) << 28) | dslot) << 32) | (u64)didx;
+    lx = x; lrec = ((u64)(((dflag | mnull | pre | dlatch) << 28) | dslot) << 32) | (u64)didx;
+    return true;
+}
+#define ADD_DEP_BLK 1024
+__global__ __launch_bounds__(ADD_DEP_BLK) void k_add_dep(Dev d, u64 n, const u64 *src, const u64 *dst, const u32 *slot, const u32 *mode, u32 nanny) {
+    __shared__ u32 lds[18];
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    u32 lx = 0; u64 lrec = 0;
+    const bool reg = i < n && add_dep_one(d, i, src, dst, slot, mode, nanny, lx, lrec);
+    const u32 li = block_append(&d.ctrl->log_tail, reg, lds);
+    if (!reg) return;
+    if ((u64)li + d.ctrl->chan_wait_used >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // waiters[] top end = CHANNEL rings
+    d.log_src[li] = lx; d.log_rec[li] = lrec;
 }
 
 __global__ void k_satisfy(Dev d, u64 n, const u64 *evt, const u64 *db, const u32 *slot) {
@@ -2487,29 +2518,44 @@ __global__ void k_reclaim_lazy_users(Dev d, ReclDev rc, u32 n_edt) {
 // bodies: handed out by ocrgpu_pop_ready before this call), whose ONCE output event is gone and whose output datablock has
 // been destroyed gives its line and its guids back (destructTaskHc, hc-task.c:721-790).  What cannot go yet is kept in
 // held_new; host-body EDTs not handed out yet stay in the ready log (`unpopped`).
-__global__ void k_reclaim_edts(Dev d, ReclDev rc, u32 n_held, u32 r_end, u32 pop_cursor, u32 n_free, u32 *unpopped) {
+#define RECL_BLK 1024
+__global__ __launch_bounds__(RECL_BLK) void k_reclaim_edts(Dev d, ReclDev rc, u32 n_held, u32 r_end, u32 pop_cursor, u32 n_free, u32 *unpopped) {
+    __shared__ u32 lds[18];
     const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i >= (u64)n_held + r_end) return;
-    const bool from_log = i >= n_held;
-    const u32 e = from_log ? d.fired[i - n_held] : rc.held[i];
-    if (e == INVALID) return;
-    EdtLine *L = &d.edt[e];
-    const u32 pending = L->pending, body = L->body, out_state = L->out_state, kind = OCRBODY_KIND(body);
-    if (body & BODY_FREE) return;
-    if (kind == OCRBODY_HOST && from_log && i - n_held >= pop_cursor) { unpopped[atomicAdd(&rc.cnt[RC_UNPOPPED], 1u)] = e; return; }
-    bool ok = true;
-    if ((body & OCRBODY_F_OUTEVT) && (out_state & 0xFF) != ST_DESTROYED) ok = false;   // its output event has not fired yet
-    if (kind == OCRBODY_HASH && !(body & BODY_DB_DEAD)) ok = false;                     // its output datablock is still alive
-    if ((pending & PEND_LAZY) && rc.cnt[RC_LAZY_LIVE] != 0) ok = false;                 // lazy_tab entries of this line cannot be dropped yet
-    if (!ok) { rc.held_new[atomicAdd(&rc.cnt[RC_HELD], 1u)] = e; return; }
-    const EdtGuids g = rc.edt_guids[e];
-    if (g.edt) gtab_remove(d, g.edt);
-    if (g.oevt) gtab_remove(d, g.oevt);
-    if (g.odb) gtab_remove(d, g.odb);
-    rc.edt_guids[e] = EdtGuids{0, 0, 0, 0};
-    if (pending & PEND_LAZY) atomicAdd(&rc.cnt[RC_LAZY_FREED], 1u);
-    L->pending = 0u; L->level = 0u; L->body = BODY_FREE; L->out_state = (u32)ST_ABSENT;
-    rc.free_edt[n_free + atomicAdd(&rc.cnt[RC_EDT], 1u)] = e;
+    u32 e = INVALID;
+    bool freed = false, held = false;
+    if (i < (u64)n_held + r_end) {
+        const bool from_log = i >= n_held;
+        e = from_log ? d.fired[i - n_held] : rc.held[i];
+        if (e != INVALID) {
+            EdtLine *L = &d.edt[e];
+            const u32 pending = L->pending, body = L->body, out_state = L->out_state, kind = OCRBODY_KIND(body);
+            if (body & BODY_FREE) { }
+            else if (kind == OCRBODY_HOST && from_log && i - n_held >= pop_cursor) unpopped[atomicAdd(&rc.cnt[RC_UNPOPPED], 1u)] = e;
+            else {
+                bool ok = true;
+                if ((body & OCRBODY_F_OUTEVT) && (out_state & 0xFF) != ST_DESTROYED) ok = false;   // its output event has not fired yet
+                if (kind == OCRBODY_HASH && !(body & BODY_DB_DEAD)) ok = false;                     // its output datablock is still alive
+                if ((pending & PEND_LAZY) && rc.cnt[RC_LAZY_LIVE] != 0) ok = false;                 // lazy_tab entries of this line cannot be dropped yet
+                if (!ok) held = true;
+                else {
+                    const EdtGuids g = rc.edt_guids[e];
+                    if (g.edt) gtab_remove(d, g.edt);
+                    if (g.oevt) gtab_remove(d, g.oevt);
+                    if (g.odb) gtab_remove(d, g.odb);
+                    rc.edt_guids[e] = EdtGuids{0, 0, 0, 0};
+                    if (pending & PEND_LAZY) atomicAdd(&rc.cnt[RC_LAZY_FREED], 1u);
+                    L->pending = 0u; L->level = 0u; L->body = BODY_FREE; L->out_state = (u32)ST_ABSENT;
+                    freed = true;
+                }
+            }
+        }
+    }
+    // one atomic per workgroup and list (block_append): 50M lines going back one wavefront at a time spent 24 ms on rc.cnt[RC_EDT] alone
+    const u32 hi = block_append(&rc.cnt[RC_HELD], held, lds);
+    if (held) rc.held_new[hi] = e;
+    const u32 fi = block_append(&rc.cnt[RC_EDT], freed, lds);
+    if (freed) rc.free_edt[n_free + fi] = e;
 }
 // destructEventHc (hc-event.c:185-242): a destroyed event's record and guid go back
 __global__ void k_reclaim_evts(Dev d, ReclDev rc, u32 n_evt, u32 n_free) {
@@ -2551,9 +2597,13 @@ __global__ void k_log_back(Dev d, const u32 *tsrc, const u64 *trec, const u32 *k
 }
 // The ready log starts over: [host-body EDTs that fired but were not handed out yet][EDTs that are ready and have not fired].
 __global__ void k_ready_gather(Dev d, ReclDev rc, u32 r_end, u32 r_tail, u32 *ready) {
-    for (u64 i = r_end + blockIdx.x * (u64)blockDim.x + threadIdx.x; i < r_tail; i += (u64)gridDim.x * blockDim.x) {
-        const u32 e = d.fired[i];
-        if (e != INVALID) ready[atomicAdd(&rc.cnt[RC_READY], 1u)] = e;
+    __shared__ u32 lds[18];
+    const u64 span = (u64)r_tail - r_end, stride = (u64)gridDim.x * blockDim.x;
+    for (u64 o = 0; o < span; o += stride) { // every thread of a workgroup makes the same number of trips (block_append has barriers)
+        const u64 i = o + blockIdx.x * (u64)blockDim.x + threadIdx.x;
+        const u32 e = i < span ? d.fired[r_end + i] : INVALID;
+        const u32 ri = block_append(&rc.cnt[RC_READY], e != INVALID, lds);
+        if (e != INVALID) ready[ri] = e;
     }
 }
 __global__ void k_ready_back(Dev d, ReclDev rc, const u32 *unpopped, const u32 *ready) {
@@ -3214,7 +3264,7 @@ extern "C" int ocrgpu_add_dependence(ocrgpu_engine_t *e, u64 n, const u64 *src, 
         if ((r = stage_in(e, src + o, m, where, &ds)) || (r = stage_in(e, dst + o, m, where, &dd)) || (r = stage_in(e, slot + o, m, where, &dsl)) ||
             (r = stage_in(e, mode + o, m, where, &dm))) return r;
         // registrations first, then the immediate satisfies this batch produced (see DESIGN.md "batch order")
-        k_add_dep<<<nblk(m), 256, 0, e->stream>>>(e->d, m, ds, dd, dsl, dm, (e->cfg.flags & OCRGPU_F_NANNY) ? 1u : 0u);
+        k_add_dep<<<(u32)((m + ADD_DEP_BLK - 1) / ADD_DEP_BLK), ADD_DEP_BLK, 0, e->stream>>>(e->d, m, ds, dd, dsl, dm, (e->cfg.flags & OCRGPU_F_NANNY) ? 1u : 0u);
         HIPCHK(hipGetLastError());
         e->edges_upper += m; e->csr_dirty = true;
         if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream)); // staging buffers are reused by the next chunk / call
@@ -3292,7 +3342,7 @@ extern "C" int ocrgpu_reclaim(ocrgpu_engine_t *e, ocrgpu_reclaim_t *out) {
     HIPCHK(hipMemsetAsync(rc.cnt, 0, 4 * RC_N, e->stream));
     if (e->n_edt) k_reclaim_lazy_users<<<nblk(e->n_edt), 256, 0, e->stream>>>(d, rc, e->n_edt);
     const u64 n_cand = (u64)e->n_held + r_end;
-    if (n_cand) k_reclaim_edts<<<nblk(n_cand), 256, 0, e->stream>>>(d, rc, e->n_held, r_end, pop_cursor, e->n_free_edt, e->tmp_a);
+    if (n_cand) k_reclaim_edts<<<nblk(n_cand, RECL_BLK), RECL_BLK, 0, e->stream>>>(d, rc, e->n_held, r_end, pop_cursor, e->n_free_edt, e->tmp_a);
     if (e->n_evt) k_reclaim_evts<<<nblk(e->n_evt), 256, 0, e->stream>>>(d, rc, e->n_evt, e->n_free_evt);
     if (e->n_edt) k_reclaim_pool_users<<<nblk(e->n_edt), 256, 0, e->stream>>>(d, rc, e->n_edt);
     // the registration log (the rows are rebuilt from it by the next run)
