@@ -90,7 +90,12 @@ typedef struct {
 #define OCRGPU_F_WIDE_DB 16u /* every ocrgpu_db_create datablock also carries an 8x8 tile of 64-bit integers (512 bytes, word w =
                               * ocrops_tile_init(value, w)) that OCRBODY_TILE bodies update in place -- the payload SURVEY.md s8d.3 names
                               * for the tiled Cholesky (regular-datablock.c:55-215: a datablock is its guid + a buffer the EDT writes).
-                              * ocrgpu_read_dbs reports ocrops_tile_checksum of the tile.  One partition only.                        */
+                              * ocrgpu_read_dbs reports ocrops_tile_checksum of the tile.  Across partitions (ocrgpu_exchange_config) a
+                              * satisfy that carries such a datablock carries the WHOLE datablock, as hc-dist clones it on a remote acquire
+                              * (ProxyDb_t, hc-dist-policy.c:382-700): it takes 23 slots of the destination's send region (head + tile +
+                              * home guid) instead of one, the receiver keeps a copy under the home guid (or takes the contents in place when
+                              * the datablock comes home), and a TILE body that updated a copy sends the contents home (23 more slots: the
+                              * write-back of a released RW / EW proxy).  Size records_per_dest and max_db (one copy per arriving tile) for it. */
 #define OCRGPU_F_LOCKABLE_DB 8u /* the cfg's datablockfactory=Lockable instead of Regular: an EDT whose pre-slots are all
                                  * satisfied first acquires its datablocks, in ascending guid order, each once, in the mode
                                  * its ocrAddDependence named (DB_MODE_CONST / RW / EW / RO), waits in line on a busy one

@@ -105,6 +105,16 @@ static_assert(sizeof(SendRec) == 32, "SendRec is 32 bytes");
 #define XF_DESTROY 4u    // ocrEventDestroy of an event owned by another partition
 #define XF_LAZYREG 16u   // guid/slot = an EDT pre-slot here; value = guid of the COUNTED event (there) registered on it
 #define XF_ACTIVATE 32u  // guid = a COUNTED event here: a held-back registration of a remote EDT has now been made
+// Tile datablocks (OCRGPU_F_WIDE_DB) cross by value too -- the whole datablock, as hc-dist's ProxyDb_t clones it on a remote acquire
+// (hc-dist-policy.c:382-700).  A record that carries one is a HEAD slot followed by 22 continuation slots in the same region: slot k
+// holds words 3k, 3k+1, 3k+2 of {64 tile words, the guid the datablock was created under} in its guid / value / tag fields and
+// XF_CONT in its flags, so every transport moves tiles as the 32-byte slots it already moves and the apply kernels' one-thread-per-slot
+// walk skips what is not a head.
+#define XF_HAS_TILE 64u  // head: the 22 slots behind it carry the datablock's tile and its home guid
+#define XF_CONT 128u     // continuation slot (not a record of its own)
+#define XF_TILE_WB 256u  // head (with XF_HAS_TILE): guid = a datablock HERE; a TILE body updated a copy of it elsewhere and its contents come
+                         // home (the write-back of a released RW / EW proxy, hc-dist-policy.c PD_MSG_DB_RELEASE); satisfies nothing
+#define TILE_REC_SLOTS 23u
 #define RF_REMOTE 8u     // waiter flag (with bit0 clear): lo = index into rdst[]; bit2 = dst is an EDT, bit1 = MODE_NULL
 struct RemoteDst { u64 guid; u32 slot, flags; };
 
@@ -138,7 +148,9 @@ struct alignas(128) Ctrl {
     DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB only (else null): lock word + waiter lists per datablock; access mode per
                                           // EDT pre-slot.  Kept here, not in Dev: the hot kernel's argument block stays as small as it was
     u64 *tiles;                 // OCRGPU_F_WIDE_DB only (else null): the 8x8 tile of 64-bit integers behind datablock i at tiles[64 * i]
-    u32 pad5[18];
+    u64 *db_home;               // OCRGPU_F_WIDE_DB only: the guid datablock i was created under -- its own, or for a copy that a record
+                                // brought in (a proxy) the guid of the original on its home partition
+    u32 pad5[16];
     // during a run
     State state[2];
     Cnt cnt_r[3], cnt_q[3];     // launch K appends through cnt_*[K%3]; launch K+1 reads them; launch K zeroes [(K+1)%3]
@@ -691,12 +703,31 @@ __device__ __forceinline__ ulonglong2 db_gather(const Dev &d, u32 p) {
 // AGG: the reservation is shared by the lanes of the wavefront (below).  Only the fan-out asks for it, and not in the tile-body
 // instantiation of k_step (tile engines have one partition; the code inlined there cost it 70 VGPRs and a wave of occupancy).
 template <bool AGG> __device__ __forceinline__ void emit_remote_record(const Dev &d, u64 guid, u32 slot, u32 xflags, u64 value, u64 tag);
-template <bool AGG = false>
+// a record that carries tile datablock `dbi` (index in db[] / tiles[]): head + continuation slots, reserved together
+__device__ void emit_remote_tile(const Dev &d, u64 guid, u32 slot, u32 xflags, ulonglong2 b, u32 dbi) {
+    const u32 loc = OCRGPU_GUID_LOCATION(guid);
+    if (d.send == nullptr || loc >= d.n_loc) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
+    const u32 pos = atomicAdd(&d.send_cnt[loc * 32], TILE_REC_SLOTS);
+    if ((u64)pos + TILE_REC_SLOTS + 1 > d.send_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // (the last slot of a region is its header)
+    SendRec *r = d.send + (size_t)loc * d.send_cap + pos;
+    r[0] = SendRec{guid, slot, xflags | XF_HAS_DB | XF_HAS_TILE, b.x, b.y};
+    const u64 *t = d.ctrl->tiles + OCROPS_TILE_WORDS * (size_t)dbi;
+    const u64 home = d.ctrl->db_home[dbi];
+    auto word = [&](u32 w) -> u64 { return w < OCROPS_TILE_WORDS ? t[w] : w == OCROPS_TILE_WORDS ? home : 0ull; };
+#pragma unroll 2
+    for (u32 k = 0; k + 1 < TILE_REC_SLOTS; ++k) r[1 + k] = SendRec{word(3 * k), k, XF_CONT, word(3 * k + 1), word(3 * k + 2)};
+}
+// XT: the caller may meet tile datablocks that cross partitions (compiled out of the k_step instantiations that cannot: the code costs
+// the tile-body kernel a wave of occupancy and spills; tests/test_kernel_resources.py holds the one-partition kernels to what they had)
+template <bool AGG = false, bool XT = true>
 __device__ __forceinline__ void emit_remote(const Dev &d, u64 guid, u32 slot, u32 xflags, u32 payload) {
     u32 loc = OCRGPU_GUID_LOCATION(guid);
     if (d.send == nullptr || loc >= d.n_loc) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
     ulonglong2 b = make_ulonglong2(0, 0);
     if (payload && !(xflags & XF_MODE_NULL)) { b = db_gather(d, payload); xflags |= XF_HAS_DB; }
+    if (XT && !AGG) { // (the wavefront-aggregated form is the fan-out of the engines WITHOUT tile datablocks)
+        if ((xflags & XF_HAS_DB) && payload - 1 < d.max_db && d.ctrl->tiles) { emit_remote_tile(d, guid, slot, xflags, b, payload - 1); return; }
+    }
     emit_remote_record<AGG>(d, guid, slot, xflags, b.x, b.y);
 }
 __device__ void emit_remote_raw(const Dev &d, u64 guid, u32 slot, u32 xflags, u64 value, u64 tag) { emit_remote_record<false>(d, guid, slot, xflags, value, tag); }
@@ -737,7 +768,7 @@ __device__ __forceinline__ void emit_remote_record(const Dev &d, u64 guid, u32 s
 // consecutive entries of the ready log up front (one atomic, issued before the waiter loads so it costs no
 // extra round trip) and lane t writes entry t: the EDT it made ready, or INVALID.  Compaction happens on
 // the read side (the FIRE pass skips holes), where it is a ballot instead of a dependent atomic.
-template <bool NANNY, bool LOCKABLE, bool TILES>
+template <bool NANNY, bool LOCKABLE, int TILES>
 __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 total, u32 *lds_base, u64 &n_edt_sat, u64 &n_evt_sat) {
     Ctrl *c = d.ctrl;
     u32 rbase = 0;
@@ -767,7 +798,7 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         if (__ballot(is_latch)) latch_issue(d, is_latch, dst, slot, l_lead, l_old, l_delta);
         if (act) {
             if (flags & RF_DST_EDT) ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, dst, slot, payload, flags);
-            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote<!TILES>(d, rd.guid, rd.slot, rd.flags, payload); }
+            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote<TILES == 0, TILES == 2>(d, rd.guid, rd.slot, rd.flags, payload); }
         }
         // statistics are wave totals (one ballot each), so the epilogue needs no cross-lane reduction
         n_edt_sat += __popcll(__ballot(act && (flags & RF_DST_EDT))); n_evt_sat += __popcll(__ballot(to_evt));
@@ -894,7 +925,7 @@ __device__ void tile_bodies_wave(const Dev &d, bool has, u32 e, const u32 (&t)[3
 
 // the per-lane part of a deferred body: the EDT's line, its pre-slot words, and (unless it is a TILE body, which the whole wave
 // runs afterwards) the gathers and the fold
-template <bool TILES>
+template <int TILES>
 __device__ __forceinline__ void deferred_body(const Dev &d, u32 e, bool &tile, u32 (&tt)[3]) {
     const EdtLine L = d.edt[e];
     if (OCRBODY_KIND(L.body) == OCRBODY_HOST) return;
@@ -913,7 +944,7 @@ __device__ __forceinline__ void deferred_body(const Dev &d, u32 e, bool &tile, u
     for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
     run_body(d, e, L.param0, L.depc, sl, gb, L.body);
 }
-template <bool TILES>
+template <int TILES>
 __device__ void deferred_bodies(const Dev &d, u32 b_begin, u32 b_end, u32 h, u32 nh) {
     bool tile = false; u32 tt[3] = {0, 0, 0};
     if (!TILES) { // every lane for itself
@@ -944,7 +975,7 @@ __device__ void deferred_bodies(const Dev &d, u32 b_begin, u32 b_end, u32 h, u32
 // One launch = one phase.  K is the launch index (host counter): it selects the state / counter buffers.
 // TILES (OCRGPU_F_WIDE_DB): OCRBODY_TILE bodies are compiled in -- a variant of its own, so that the default kernel keeps
 // its registers (118 VGPRs, 4 waves per SIMD; with the tile code inline: 137 and 3).
-template <bool NANNY, bool LOCKABLE, bool TILES>
+template <bool NANNY, bool LOCKABLE, int TILES>
 __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #ifdef OCRGPU_STAMPS
     u64 _t0 = __builtin_amdgcn_s_memrealtime();
@@ -1092,13 +1123,13 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                             u32 pay = pk == OCRGPU_PAY_GUID ? sc.payload : pk == OCRGPU_PAY_OUTDB ? d.max_db + e + 1
                                     : pk == OCRGPU_PAY_DEPV ? (sl[sc.payload] & 0x7FFFFFFFu) : 0u;
                             if (sc.op_kind & 0x10000u) { // the event lives on another partition
-                                RemoteDst rd = d.rdst[sc.target]; emit_remote(d, rd.guid, rd.slot, 0u, pay); continue;
+                                RemoteDst rd = d.rdst[sc.target]; emit_remote<false, TILES == 2>(d, rd.guid, rd.slot, 0u, pay); continue;
                             }
                             u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
                             if (qi < d.q_cap) d.q[qi] = Rec{sc.target, pay, sc.slot, 0u};
                             else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
                         } else if (sc.op_kind & 0x10000u) { // ocrEventDestroy of a remote event
-                            RemoteDst rd = d.rdst[sc.target]; emit_remote(d, rd.guid, 0u, XF_DESTROY, 0u);
+                            RemoteDst rd = d.rdst[sc.target]; emit_remote<false, false>(d, rd.guid, 0u, XF_DESTROY, 0u);
                         } else { // ocrEventDestroy
                             u32 old = atomicExch(evt_state(d, sc.target), (u32)ST_DESTROYED);
                             if ((old & 0xFF) != ST_LIVE && (old & 0xFF) != ST_SAT) atomicAdd(&c->err[ERR_DEAD_EVENT], 1u);
@@ -1119,6 +1150,20 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                 }
             }
             n_fired += __popcll(__ballot(mine)); n_evt_sat += __popcll(__ballot(epi));
+            if (TILES == 2 && body_first) {
+                // With other partitions around the fan-out below carries this level's tiles away BY VALUE, so the TILE bodies run first
+                // (they are wave-wide: here, outside the per-lane block above); the barrier makes what they stored visible to the other
+                // waves of the workgroup, whose lanes write the records (edge-balanced fan-out: not the EDT's own lane).  A body that
+                // updated a COPY of another partition's datablock sends the contents home (hc-dist writes a released RW / EW proxy back).
+                const bool tb = mine && OCRBODY_KIND(body) == OCRBODY_TILE;
+                tile_bodies_wave(d, tb, e, tt);
+                __syncthreads();
+                const u32 tg = tb ? tile_target(tt) : 0u;
+                if (tg && tg - 1 < d.max_db) {
+                    const u64 home = c->db_home[tg - 1];
+                    if (OCRGPU_GUID_LOCATION(home) != d.location) emit_remote_tile(d, home, 0u, XF_TILE_WB, d.db[tg - 1], tg - 1);
+                }
+            }
             STAMP(1);
             u32 total;
             u32 incl = block_inclusive_scan(deg, wave_sums, total);
@@ -1129,7 +1174,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (total) fan_out<NANNY, LOCKABLE, TILES>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             STAMP(3);
             if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST && OCRBODY_KIND(body) != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, body);
-            if (TILES) tile_bodies_wave(d, mine && !defer && OCRBODY_KIND(body) == OCRBODY_TILE, e, tt);
+            if (TILES && !(TILES == 2 && body_first)) tile_bodies_wave(d, mine && !defer && OCRBODY_KIND(body) == OCRBODY_TILE, e, tt);
         }
     } else {
         // ---- queued satisfies: API calls, fired chained events, big-row pieces, direct EDT pre-slot satisfies ----
@@ -1813,6 +1858,7 @@ __global__ void k_db_create(Dev d, ReclDev rc, u32 n_free, u32 n_take, u64 n, co
     // issued here carry by value (the proxy DBs of the reference's distributed PD, hc-dist-policy.c:382-440)
     if (gin && (OCRGPU_GUID_KIND(g) != OCRGPU_KIND_DB || OCRGPU_GUID_COUNTER(g) == 0)) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
     gtab_put(d, g, (u64)x + 1);
+    if (d.ctrl->db_home) d.ctrl->db_home[x] = g; // (a given guid of another location: this entry is a copy, and what a TILE body does to it goes home)
     if (guids_out) guids_out[i] = g;
 }
 // OCRGPU_F_WIDE_DB: the tile behind each datablock the call created (same index rule as k_db_create), one thread per word
@@ -2144,7 +2190,31 @@ __device__ __forceinline__ u32 wave_reserve_one(u32 *counter) {
     if (lane == leader) base = atomicAdd(counter, (u32)__popcll(m));
     return __shfl(base, leader) + (u32)__popcll(m & ((1ull << lane) - 1ull));
 }
-__device__ void apply_record(const Dev &d, const SendRec &r, u32 db_floor) {
+// the tile behind a head slot -> tiles[idx]; returns the home guid the record names
+__device__ __forceinline__ u64 tile_from_record(const Dev &d, const SendRec *head, u32 idx) {
+    u64 *t = d.ctrl->tiles + OCROPS_TILE_WORDS * (size_t)idx;
+    u64 home = 0;
+#pragma unroll 2
+    for (u32 k = 0; k + 1 < TILE_REC_SLOTS; ++k) {
+        const SendRec c = head[1 + k];
+        const u64 w[3] = {c.guid, c.value, c.tag};
+#pragma unroll
+        for (u32 j = 0; j < 3; ++j) { const u32 i = 3 * k + j; if (i < OCROPS_TILE_WORDS) t[i] = w[j]; else if (i == OCROPS_TILE_WORDS) home = w[j]; }
+    }
+    return home;
+}
+__device__ __forceinline__ u64 tile_record_home(const SendRec *head) { return head[1 + OCROPS_TILE_WORDS / 3].value; } // word 64 = slot 21, second field
+// `avail` = slots from this one to the end of what arrived in its region (a head's continuation slots must lie within it)
+__device__ void apply_record(const Dev &d, const SendRec *rp, u32 avail, u32 db_floor) {
+    const SendRec r = *rp;
+    if (r.flags & XF_CONT) return; // part of the head in front of it
+    if ((r.flags & XF_HAS_TILE) && (avail < TILE_REC_SLOTS || !d.ctrl->tiles)) { bad_op(d); return; }
+    if (r.flags & XF_TILE_WB) { // a copy of one of OUR datablocks was updated elsewhere: its contents come home
+        const u64 v = (OCRGPU_GUID_LOCATION(r.guid) == d.location && OCRGPU_GUID_KIND(r.guid) == OCRGPU_KIND_DB && (r.flags & XF_HAS_TILE)) ? gtab_get(d, r.guid) : 0;
+        if (!v || v - 1 >= d.max_db) { bad_op(d); return; }
+        tile_from_record(d, rp, (u32)(v - 1));
+        return;
+    }
     if (r.flags & XF_DESTROY) {
         u64 v = (OCRGPU_GUID_LOCATION(r.guid) == d.location && is_event_kind(OCRGPU_GUID_KIND(r.guid))) ? gtab_get(d, r.guid) : 0;
         if (!v) { bad_op(d); return; }
@@ -2160,11 +2230,17 @@ __device__ void apply_record(const Dev &d, const SendRec &r, u32 db_floor) {
     }
     // (the proxy entry of a record that carries a datablock is reserved in front of the table lookup: the two trips overlap)
     u32 pay = 0;
-    if ((r.flags & XF_HAS_DB) && !(r.flags & XF_LAZYREG)) { // only a record that carries a datablock takes a proxy entry
+    const u64 home = (r.flags & XF_HAS_TILE) ? tile_record_home(rp) : 0ull;
+    if (home && OCRGPU_GUID_LOCATION(home) == d.location) { // one of OUR tile datablocks comes back with what was done to it elsewhere: no copy, the original
+        const u64 v = gtab_get(d, home);
+        if (!v || v - 1 >= d.max_db) { bad_op(d); return; }
+        tile_from_record(d, rp, (u32)(v - 1)); pay = (u32)v;
+    } else if ((r.flags & XF_HAS_DB) && !(r.flags & XF_LAZYREG)) { // only a record that carries a datablock takes a proxy entry
         const u32 pi = wave_reserve_one(&d.ctrl->proxy_used);
         if ((u64)pi + 1 + db_floor > d.max_db) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
         const u32 proxy = d.max_db - 1u - pi;
         d.db[proxy] = make_ulonglong2(r.value, r.tag); pay = proxy + 1;
+        if (r.flags & XF_HAS_TILE) { tile_from_record(d, rp, proxy); d.ctrl->db_home[proxy] = home; }
     }
     u32 didx, dslot, dflag;
     if (OCRGPU_GUID_LOCATION(r.guid) != d.location || !resolve_dst(d, r.guid, r.slot, didx, dflag, dslot)) { bad_op(d); return; }
@@ -2187,7 +2263,7 @@ __device__ void apply_record(const Dev &d, const SendRec &r, u32 db_floor) {
 }
 __global__ void k_exchange_apply(Dev d, u64 n, const SendRec *recs, u32 db_floor) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (i < n) apply_record(d, recs[i], db_floor);
+    if (i < n) apply_record(d, recs + i, (u32)(n - i > 0xFFFFFFFFull ? 0xFFFFFFFFull : n - i), db_floor);
 }
 // one receive buffer of n_src regions of `stride` records (an equal-split all-to-all): region s holds cnt[s] records,
 // cnt[n_src + s] = records in the regions before it
@@ -2195,7 +2271,7 @@ __global__ void k_exchange_apply_strided(Dev d, u32 n_src, u64 stride, u32 max_c
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     u32 s = (u32)(i / max_cnt), k = (u32)(i % max_cnt);
     if (s >= n_src || k >= cnt[s]) return;
-    apply_record(d, recs[(u64)s * stride + k], db_floor);
+    apply_record(d, recs + ((u64)s * stride + k), cnt[s] - k, db_floor);
 }
 // OCRGPU_STEP_WRITE_HEADERS: {records for this destination, my activity} in the last record slot of every region
 // (end != 0: the run's k_end rides along on lane 0 -- it folds Ctrl.state[K & 1] into the between-runs words and changes nothing the headers read)
@@ -2284,7 +2360,7 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
     if (ok) {
         u64 cnt = recs[(u64)s * stride + (stride - 1)].guid; // header word 0
         if (cnt > stride - 1) cnt = stride - 1;
-        for (u64 k = part * (u64)blockDim.x + threadIdx.x; k < cnt; k += per * (u64)blockDim.x) apply_record(d, recs[(u64)s * stride + k], db_floor);
+        for (u64 k = part * (u64)blockDim.x + threadIdx.x; k < cnt; k += per * (u64)blockDim.x) apply_record(d, recs + ((u64)s * stride + k), (u32)(cnt - k), db_floor);
     }
     // (every wave waits for its own stores -- the explicit s_waitcnt: a workgroup-scope release compiles to no vector-memory wait on
     // this target -- the barrier joins them, ONE lane releases for the workgroup at device scope: a release is cumulative over what
@@ -2716,7 +2792,7 @@ struct ocrgpu_engine {
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
     u32 *pinned_done, *pinned_dev; u32 apply_flip; hipEvent_t apply_ev[2]; // the polled page and the device's address of it (k_report)
     DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB: the device tables (the device finds them through Ctrl)
-    u64 *tiles;                           // OCRGPU_F_WIDE_DB: 64 words per explicit datablock (through Ctrl as well)
+    u64 *tiles, *db_home;                 // OCRGPU_F_WIDE_DB: 64 words per explicit datablock, and the guid each was created under (through Ctrl as well)
     u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
     // comm-platform over RCCL (ocrgpu_comm_*): communicator of this partition, receive regions, a small device word block
     void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records;
@@ -2834,7 +2910,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->seal_epoch = 0; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->snap.dbl = nullptr; e->snap.tiles = nullptr; e->have_events = false;
-    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr; e->dbl = nullptr; e->acq_mode = nullptr; e->tiles = nullptr;
+    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr; e->dbl = nullptr; e->acq_mode = nullptr; e->tiles = nullptr; e->db_home = nullptr;
     e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->pop_cursor = e->snap_pop_cursor = 0; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
     { const char *mp = getenv("OCRGPU_SPREAD_WGS"); u32 v = mp ? (u32)atoi(mp) : 256u; d.spread_wgs = v < 1 ? 1u : (v > MAX_GRID ? (u32)MAX_GRID : v); }
@@ -2875,7 +2951,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.log_rec, 8 * (size_t)d.max_edges));
     TRY(dalloc(e, (void **)&d.db, 16 * (size_t)n_db_total));
     if ((cfg->flags & OCRGPU_F_WIDE_DB) && (cfg->flags & OCRGPU_F_LOCKABLE_DB)) { ocrgpu_fini(e); FAIL(OCRGPU_EINVAL, "OCRGPU_F_WIDE_DB and OCRGPU_F_LOCKABLE_DB cannot be combined"); }
-    if (cfg->flags & OCRGPU_F_WIDE_DB) TRY(dalloc(e, (void **)&e->tiles, 8 * OCROPS_TILE_WORDS * (size_t)cfg->max_db));
+    if (cfg->flags & OCRGPU_F_WIDE_DB) { TRY(dalloc(e, (void **)&e->tiles, 8 * OCROPS_TILE_WORDS * (size_t)cfg->max_db)); TRY(dalloc(e, (void **)&e->db_home, 8 * (size_t)cfg->max_db)); }
     if (cfg->flags & OCRGPU_F_LOCKABLE_DB) {
         TRY(dalloc(e, (void **)&e->dbl, sizeof(DbLock) * (size_t)n_db_total));
         TRY(dalloc(e, (void **)&e->acq_mode, (size_t)cfg->max_edt * INLINE_SLOTS + (size_t)d.max_slots));
@@ -2924,7 +3000,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     }
     // ctrl.level starts at -1 (main-program satisfies are "level -1")
     Ctrl h; memset(&h, 0, sizeof h); h.level = 0xFFFFFFFFu; h.state[0].done = h.state[1].done = 1;
-    h.dbl = e->dbl; h.acq_mode = e->acq_mode; h.tiles = e->tiles;
+    h.dbl = e->dbl; h.acq_mode = e->acq_mode; h.tiles = e->tiles; h.db_home = e->db_home;
     if (hipMemcpyAsync(d.ctrl, &h, sizeof h, hipMemcpyHostToDevice, e->stream) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "ctrl init failed"); }
     // u32 index: [0,32) the polled State; [32, 32 + 32*1024) send counters of up to 1024 locations; [33000, 34000) small read-backs
     if (hipHostMalloc((void **)&e->pinned_done, 4 * 34816, hipHostMallocMapped) != hipSuccess) { ocrgpu_fini(e); FAIL(OCRGPU_EHIP, "hipHostMalloc failed"); }
@@ -3026,9 +3102,10 @@ static int seal(ocrgpu_engine *e) {
 static void launch_step(ocrgpu_engine *e, u32 grid, u32 K) {
     const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
     const Dev &d = e->d;
-    if (e->tiles) { if (nanny) k_step<true, false, true><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false, true><<<grid, BLK, 0, e->stream>>>(d, K); }
-    else if (e->dbl) { if (nanny) k_step<true, true, false><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, true, false><<<grid, BLK, 0, e->stream>>>(d, K); }
-    else if (nanny) k_step<true, false, false><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false, false><<<grid, BLK, 0, e->stream>>>(d, K);
+    if (e->tiles && d.n_loc > 1) { if (nanny) k_step<true, false, 2><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false, 2><<<grid, BLK, 0, e->stream>>>(d, K); } // tile datablocks that cross partitions
+    else if (e->tiles) { if (nanny) k_step<true, false, 1><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false, 1><<<grid, BLK, 0, e->stream>>>(d, K); }
+    else if (e->dbl) { if (nanny) k_step<true, true, 0><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, true, 0><<<grid, BLK, 0, e->stream>>>(d, K); }
+    else if (nanny) k_step<true, false, 0><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false, 0><<<grid, BLK, 0, e->stream>>>(d, K);
 }
 static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool timing, u32 force_level = 0, u32 first_batch = 0) {
     Dev &d = e->d;
@@ -3614,7 +3691,6 @@ extern "C" int ocrgpu_step_info(ocrgpu_engine_t *e, u64 *out4) {
 extern "C" int ocrgpu_exchange_config(ocrgpu_engine_t *e, u32 n_locations, void *send_dev_buf, u64 records_per_dest, u64 max_remote_dsts) {
     ENTER(e);
     if (e->dbl) FAIL(OCRGPU_EINVAL, "OCRGPU_F_LOCKABLE_DB arbitrates within one partition: not with an exchange configured");
-    if (e->tiles && n_locations > 1) FAIL(OCRGPU_EINVAL, "OCRGPU_F_WIDE_DB: records carry 16-byte datablocks by value; tile datablocks stay within one partition");
     if (n_locations == 0 || n_locations > 1024 || e->cfg.location >= n_locations) FAIL(OCRGPU_EINVAL, "bad n_locations");
     if (n_locations > 1 && (records_per_dest == 0 || records_per_dest > 0xFFFFFFFFull)) FAIL(OCRGPU_EINVAL, "records_per_dest must be in [1, 2^32)");
     Dev &d = e->d;

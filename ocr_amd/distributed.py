@@ -19,10 +19,11 @@ import torch  # noqa: F401
 import numpy as np
 
 from . import opstream as ops
-from .engine import SCRIPT_OP_DT, Engine
+from .engine import F_WIDE_DB, SCRIPT_OP_DT, Engine
 from .opstream import OpStream, Result
 
 REC_BYTES = 32
+TILE_REC_SLOTS = 23   # slots of a record that carries a tile datablock (ocrgpu.hip: head + 22 slots of 3 words = 64 tile words + home guid)
 KIND_DB, KIND_EDT = 2, 3
 EVT_GUID_KIND = {ops.EVT_ONCE: 17, ops.EVT_COUNTED: 18, ops.EVT_IDEM: 19, ops.EVT_STICKY: 21, ops.EVT_LATCH: 22,
                  ops.EVT_CHANNEL: 23}
@@ -63,7 +64,7 @@ class Partition:
     payload DB (else of the event).  GUIDs of remote objects are predicted: every engine hands out counters in
     creation order, so all ranks can compute all GUIDs from the stream alone (checked against the real ones)."""
 
-    def __init__(self, s: OpStream, rank: int, world: int, device=0, flags=0, send_cap=None, torch=None, owner_edt=None):
+    def __init__(self, s: OpStream, rank: int, world: int, device=0, flags=0, send_cap=None, torch=None, owner_edt=None, proxy_cap=None):
         """owner_edt: rank of every EDT (array of s.n_edt) in place of the hash partition -- the placement hook: an EDT's
         output event and output datablock live with it, so this decides which dependences cross partitions."""
         import torch as _torch
@@ -77,11 +78,17 @@ class Partition:
         mine_e = self.own_edt == rank
         n_my_edt = int(mine_e.sum())
         n_adddep = int((s.main["op"] == ops.OP_ADD_DEP).sum())
-        cap = send_cap or max(4096, n_adddep + len(s.script) + 1024)
+        # streams with tile datablocks (OCRGPU_F_WIDE_DB): a record that carries a datablock takes 23 slots of its region (head + the
+        # tile), and a TILE body that updated a copy sends one more home
+        tiles = s.db_words == 64
+        per_rec = TILE_REC_SLOTS if tiles else 1
+        if tiles:
+            flags |= F_WIDE_DB
+        cap = send_cap or max(4096, per_rec * (n_adddep + len(s.script) + (s.n_edt if tiles else 0)) + 1024)
         self.send_cap = cap
         self.send = self.torch.zeros((world, cap, REC_BYTES), dtype=self.torch.uint8, device=f"cuda:{device}")
         self.eng = Engine(max_edt=max(n_my_edt, 1), max_evt=max(int((self.own_evt == rank).sum()), 1),
-                          max_db=s.n_db + world * cap + 16,
+                          max_db=s.n_db + (proxy_cap if proxy_cap is not None else world * (cap // per_rec + 1)) + 16,
                           max_slots=int(s.edt["depc"][mine_e].sum()) + 1, max_edges=n_adddep + 1 + ops.channel_ring_slots(s), device=device,
                           location=rank, flags=flags)
         self.eng.exchange_config(world, self.send.data_ptr(), cap, n_adddep + len(s.script) + 16)

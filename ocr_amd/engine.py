@@ -471,8 +471,9 @@ class StreamProgram:
     """An op stream loaded into an :class:`Engine`: the same role oracle/ocr_replay.c plays for the
     reference runtime, but every op becomes (part of) one batched C-ABI call."""
 
-    def __init__(self, s: OpStream, device=0, flags=0, engine=None, slack=0, tolerate_faults=False, reuse=False):
+    def __init__(self, s: OpStream, device=0, flags=0, engine=None, slack=0, tolerate_faults=False, reuse=False, progress=None):
         self.s = s
+        self.progress = progress   # called with a line of text after every chunk of a long build (None: silent)
         # reuse: the engine may hand out reclaimed rows (ocrgpu_reclaim), so creation order is not index order: ask the
         # GUID table for every object's index right after its create call
         self.reuse = reuse
@@ -494,6 +495,8 @@ class StreamProgram:
         self.db_order = []
         self.eng.set_hash_tag_base(s.n_db)
         self._built = False
+
+    ADD_DEP_CHUNK = 1 << 26
 
     def _guids(self, refs, depv_ok=False):
         refs = np.asarray(refs, dtype=np.uint64)
@@ -542,8 +545,11 @@ class StreamProgram:
                     self.edt_index[idx] = eng.guid_get(g).astype(np.int64) - 1
             elif op == ops.OP_ADD_DEP:
                 for c0, c1 in (ops.split_conflicts(ops.channel_keys(s, blk["a"])) if ops.channel_ring_slots(s) else [(0, len(blk))]):   # registrations on one CHANNEL keep program order
-                    b = blk[c0:c1]
-                    eng.add_dependence(self._guids(b["a"]), self._guids(b["b"]), b["slot"], b["mode"].astype(np.uint32))
+                    for k0 in range(c0, c1, self.ADD_DEP_CHUNK):   # bounded host arrays; a line of progress per chunk
+                        b = blk[k0:min(c1, k0 + self.ADD_DEP_CHUNK)]
+                        eng.add_dependence(self._guids(b["a"]), self._guids(b["b"]), b["slot"], b["mode"].astype(np.uint32))
+                        if self.progress and c1 - c0 > self.ADD_DEP_CHUNK:
+                            self.progress(f"add_dependence: {min(c1, k0 + self.ADD_DEP_CHUNK) - c0} of {c1 - c0} registered")
             elif op == ops.OP_SATISFY:
                 for c0, c1 in ops.split_conflicts(blk["a"]):   # two satisfies of one event keep program order
                     b = blk[c0:c1]

@@ -594,24 +594,34 @@ def stencil_dag(G: int, steps: int, name=None) -> OpStream:
 
 
 def powerlaw_dag(n_edt: int, seed: int = SEED_BASE + 5, alpha: float = 2.1, cap: int = 1_000_000, group: int = 1024,
-                 name=None) -> OpStream:
+                 name=None, progress=None, stable_argsort=None) -> OpStream:
     """BASELINE config 5: power-law fan-out DAG with latch events.  EDT ids are a topological
     order; EDT e has out-degree ~ Zipf(alpha) (capped) to targets drawn uniformly from (e, n); every `group`
     consecutive EDTs check out of one LATCH (initial count = group size: the INCR-on-create half of a finish scope,
     hc-task.c:1071-1078, done at construction), and the group latches check out of one root latch that fires the
-    sink.  EDTs without a data predecessor hang off the start event."""
+    sink.  EDTs without a data predecessor hang off the start event.
+
+    ``progress(msg)`` is called after every stage (a 125M-EDT stream takes minutes: a caller under a silence limit prints them);
+    ``stable_argsort(keys)`` may replace numpy's stable sort of the 1e9 edge keys (tools/bench_configs.py sorts on the GPU)."""
+    say = progress or (lambda msg: None)
     N = n_edt
     u = (splitmix64(seed, N).astype(np.float64) + 0.5) / 2.0 ** 64
     deg = np.minimum(np.floor(u ** (-1.0 / (alpha - 1.0))).astype(np.int64), cap)   # P(D >= d) = d^-(alpha-1)
     deg = np.minimum(deg, N - 1 - np.arange(N))
     deg[deg < 0] = 0
     E = int(deg.sum())
+    say(f"powerlaw: {N} out-degrees drawn, {E} edges")
     src = np.repeat(np.arange(N, dtype=np.int64), deg)
     r = splitmix64(seed ^ 0x5EED, E)
     span = (N - 1 - src).astype(np.uint64)
     dst = src + 1 + (r % np.maximum(span, np.uint64(1))).astype(np.int64)
-    order = np.lexsort((src, dst))
+    del r, span
+    say("powerlaw: targets drawn")
+    # edges in (dst, src) order: src is non-decreasing as generated, so a STABLE sort by dst alone is np.lexsort((src, dst))
+    order = stable_argsort(dst) if stable_argsort is not None else np.argsort(dst, kind="stable")
     src, dst = src[order], dst[order]
+    del order
+    say("powerlaw: edges sorted by (target, source)")
     indeg = np.bincount(dst, minlength=N).astype(np.int64)
     first_of = np.zeros(N + 1, dtype=np.int64)
     np.cumsum(indeg, out=first_of[1:])
@@ -627,6 +637,7 @@ def powerlaw_dag(n_edt: int, seed: int = SEED_BASE + 5, alpha: float = 2.1, cap:
     extra = [make_ops(OP_ADD_DEP, ref(REF_OUTEVT, np.arange(N)), b=ref(REF_EVT, 3 + np.arange(N) // group), slot=LATCH_DECR, mode=MODE_NULL),
              make_ops(OP_ADD_DEP, ref(REF_EVT, 3 + np.arange(n_groups)), b=np.full(n_groups, ref(REF_EVT, 2), np.uint64), slot=LATCH_DECR, mode=MODE_NULL),
              make_ops(OP_ADD_DEP, [ref(REF_EVT, 2)], b=ref(REF_EVT, 1), slot=LATCH_DECR, mode=MODE_NULL)]
+    say("powerlaw: pre-slots assigned")
     s = _finish_stream(N, depc, ref(REF_OUTEVT, src), dst, slot, MODE_RO, extra_main=extra, evt_extra=evt_extra,
                        name=name or f"powerlaw_N{N}", start_targets=roots,
                        meta=dict(kind="powerlaw", n_edges=E, n_groups=n_groups, max_outdeg=int(deg.max())))

@@ -45,6 +45,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <time.h>
 #include "ocr_opstream.h"
 
 enum { ST_LIVE = 0, ST_SAT = 1, ST_DESTROYED = 2, ST_ABSENT = 3 };
@@ -383,7 +384,15 @@ int ocrref_run2(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt
     for (uint32_t x = 0; x < n_evt_total; ++x) E.ev[x].state = ST_ABSENT;
     memset(level, 0xFF, 4 * (size_t)h->n_edt); memset(val, 0, 8 * (size_t)h->n_edt);
 
+    /* OCRREF_PROGRESS=<seconds>: a line on stderr at most that often (a 125M-EDT stream runs for minutes; harnesses with a silence
+     * limit want to see it move).  Test infrastructure only, like the rest of this file. */
+    const char *pg = getenv("OCRREF_PROGRESS");
+    const double pg_every = pg ? atof(pg) : 0.0;
+    time_t pg_last = time(NULL);
     for (uint32_t k = 0; k < h->n_main; ++k) {
+        if (pg_every > 0 && (k & 0xFFFFF) == 0 && difftime(time(NULL), pg_last) >= pg_every) {
+            pg_last = time(NULL); fprintf(stderr, "[engine_ref] main op %u of %u\n", k, h->n_main); fflush(stderr);
+        }
         const ocrops_op_t *op = &main_ops[k];
         switch (op->op) {
         case OCROP_EVT_CREATE: { event_t *v = &E.ev[op->a]; v->kind = evt[op->a].kind; v->state = ST_LIVE;
@@ -406,7 +415,12 @@ int ocrref_run2(const ocrops_hdr_t *h, const ocrops_edt_t *edt, const ocrops_evt
     while (E.n_next) {
         free(cur); cur = E.ready_next; n_cur = E.n_next;
         E.ready_next = NULL; E.n_next = E.cap_next = 0;
-        for (size_t i = 0; i < n_cur; ++i) fire(&E, cur[i], lvl, level, val);
+        for (size_t i = 0; i < n_cur; ++i) {
+            if (pg_every > 0 && (i & 0xFFFFF) == 0 && difftime(time(NULL), pg_last) >= pg_every) {
+                pg_last = time(NULL); fprintf(stderr, "[engine_ref] level %d: EDT %zu of %zu (%llu fired so far)\n", lvl, i, n_cur, (unsigned long long)fired); fflush(stderr);
+            }
+            fire(&E, cur[i], lvl, level, val);
+        }
         acq_drain(&E); /* the level's releases are in: now the acquisitions they and its satisfies set off */
         fired += n_cur; ++lvl;
     }

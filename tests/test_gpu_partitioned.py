@@ -24,7 +24,7 @@ def run_partitioned(s, world):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("name", sorted(n for n in ALL if n not in ("layered_100k", "powerlaw_100k") and not ALL[n].db_words))   # (tile datablocks stay within one partition)
+@pytest.mark.parametrize("name", sorted(n for n in ALL if n not in ("layered_100k", "powerlaw_100k") and not ALL[n].db_words))   # (tile datablocks: tests/test_gpu_tiles_partitioned.py)
 def test_semantic_streams_are_partition_invariant(name, world):
     s = ALL[name]
     res, errs = run_partitioned(s, world)

@@ -26,7 +26,7 @@ def make(spec):
     if k == "stencil":
         return op.stencil_dag(a[0], a[1])
     if k == "powerlaw":
-        return op.powerlaw_dag(a[0])
+        return op.powerlaw_dag(a[0], progress=stage, stable_argsort=gpu_stable_argsort if a[0] >= 20_000_000 else None)
     if k == "layered":
         return op.layered_dag(a[0], a[1])
     if k == "layerednop":   # config 2's DAG with NOP bodies: dependence resolution alone, no datablock checksums
@@ -52,6 +52,19 @@ def make(spec):
     raise SystemExit(f"unknown workload {spec}")
 
 
+def gpu_stable_argsort(keys):
+    """stable argsort of a large int64 key array on the GPU (torch as a sort routine for the TEST-DATA generator: numpy's stable sort
+    of config 5's 1.15e9 edge keys takes minutes on the host)"""
+    import torch
+    k = torch.from_numpy(keys).cuda()
+    order = torch.sort(k, stable=True).indices
+    del k
+    out = order.cpu().numpy()
+    del order
+    torch.cuda.empty_cache()
+    return out
+
+
 def stage(msg):
     """one line per finished stage, so a long run shows where it is (and a hung stage shows as silence)"""
     print(f"[bench_configs {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -69,7 +82,7 @@ def run(spec, steps=3, warmup=1, parity=True):
     built = s.with_main(s.main[:-1])
     t0 = time.time()
     lockable = spec.startswith("lockable")
-    prog = engine.StreamProgram(built, device=0, flags=engine.F_TIMING | (engine.F_LOCKABLE_DB if lockable else 0)).build()
+    prog = engine.StreamProgram(built, device=0, flags=engine.F_TIMING | (engine.F_LOCKABLE_DB if lockable else 0), progress=stage).build()
     eng = prog.eng
     eng.snapshot()
     eng.sync()
@@ -124,6 +137,7 @@ def run(spec, steps=3, warmup=1, parity=True):
     if parity:
         from oracle import ref as O            # checker only
         t0 = time.time()
+        os.environ.setdefault("OCRREF_PROGRESS", "30")   # the restatement of a 125M-EDT stream runs for minutes: one line per 30 s
         ref = O.run_restatement(s)
         got = prog.result()
         if lockable:   # who wins a datablock is a race (here and in the reference): levels through the checker, the rest exactly
