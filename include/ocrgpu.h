@@ -269,7 +269,8 @@ int ocrgpu_pop_ready(ocrgpu_engine_t *e, uint64_t max_edts, uint64_t max_deps, u
  * in a device array of FIXED size that is part of the library (2.5 MiB per GPU, held until the process ends) instead of the
  * engine's growable staging arena: the call allocates and frees nothing.  Limits: max_edts <= 32768 and
  * max_deps <= 131072, a larger request is refused with OCRGPU_EINVAL (pop in several calls, or use ocrgpu_pop_ready).
- * Every engine on one GPU shares that GPU's array: calls that overlap on one GPU (two threads, two engines) race. */
+ * Every engine on one GPU shares that GPU's array: a call that overlaps another one on the same GPU (two threads, two engines)
+ * is refused with OCRGPU_EINVAL. */
 int ocrgpu_pop_ready_noalloc(ocrgpu_engine_t *e, uint64_t max_edts, uint64_t max_deps, uint64_t *n_edts_out, uint64_t *n_deps_out,
                              uint64_t *param0_out, uint32_t *depc_out, uint32_t *dep_first_out, uint64_t *dep_guid_out,
                              uint64_t *dep_value_out);
@@ -313,8 +314,11 @@ int ocrgpu_comm_alltoall(ocrgpu_engine_t *e, const void *send_dev, void *recv_de
  *      partitions (any channel: the bytes are plain data); ocrgpu_peer_connect maps the others' windows (hipIpcOpenMemHandle for
  *      another process, the pointer itself inside one process).  From then on ocrgpu_exchange / ocrgpu_resolve_exchange (and
  *      their _local forms) move a level's records this way: only the records there are, no RCCL kernel, the wait on the device.
- *      A source that does not arrive within OCRGPU_PEER_TIMEOUT_MS (default 2000) fails the call (OCRGPU_EHIP); the round is
- *      then not applied.  All partitions must make the same sequence of exchange calls (as with the communicator).
+ *      A source that does not arrive within OCRGPU_PEER_TIMEOUT_MS (default 2000) fails the call (OCRGPU_EHIP).  The round may
+ *      then be PARTLY applied (the regions of the sources that had arrived went in), so ocrgpu_step / ocrgpu_resolve / ocrgpu_exchange /
+ *      ocrgpu_resolve_exchange refuse from then on (OCRGPU_EHIP) until ocrgpu_restore puts a snapshot back, or the caller joins fresh
+ *      windows (ocrgpu_peer_fini + export + connect) and thereby vouches for the state.
+ *      All partitions must make the same sequence of exchange calls (as with the communicator).
  *      handles = n_locations x OCRGPU_PEER_HANDLE_BYTES, in location order, this partition's own included. ------------------- */
 #define OCRGPU_PEER_HANDLE_BYTES 128
 int ocrgpu_peer_export(ocrgpu_engine_t *e, void *handle_out);

@@ -24,6 +24,7 @@
 #include <vector>
 #include <chrono>
 #include <algorithm>
+#include <atomic>
 #include <dlfcn.h>
 #include <time.h>
 #include <unistd.h>
@@ -2798,7 +2799,7 @@ struct ocrgpu_engine {
     void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records;
     // peer windows (ocrgpu_peer_*): my window, the device table of everybody's, what was opened from other processes, the round
     // counter every partition advances together, the wait limit in wall-clock ticks; hdr_fresh: the step just queued wrote the headers
-    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; u32 peer_fence_wave; bool peer_on, hdr_fresh, ahead_timed, end_pending; hipEvent_t ra_ev[2];
+    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; u32 peer_fence_wave; bool peer_on, hdr_fresh, ahead_timed, end_pending, poisoned /* a peer wait gave up: the level may be partly applied */; hipEvent_t ra_ev[2];
     u64 *wp; u64 wp_cap, wp_head, wp_tail; // workpile: ring of guids in HBM, indices kept by the (single) caller side
     // reclaimed capacity (ocrgpu_reclaim, ocrgpu_db_destroy): device tables, host mirrors of the free-stack heights and of the
     // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
@@ -2904,7 +2905,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     ocrgpu_engine *e = new ocrgpu_engine();
     e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
     e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0;
-    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_fence_wave = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false; e->ra_ev[0] = e->ra_ev[1] = nullptr;
+    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_fence_wave = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false; e->poisoned = false; e->ra_ev[0] = e->ra_ev[1] = nullptr;
     e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
     memset(&e->rc, 0, sizeof e->rc); e->n_free_edt = e->n_free_evt = e->n_free_db = e->n_held = 0; e->mut_epoch = 0; e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
@@ -3071,6 +3072,11 @@ extern "C" int ocrgpu_sync(ocrgpu_engine_t *e) { if (!e) FAIL(OCRGPU_EINVAL, "nu
 extern "C" int ocrgpu_set_hash_tag_base(ocrgpu_engine_t *e, u64 b) { if (!e) FAIL(OCRGPU_EINVAL, "null engine"); e->d.hash_tag_base = b; return 0; }
 
 #define ENTER(e) do { if (!(e)) FAIL(OCRGPU_EINVAL, "null engine"); HIPCHK(hipSetDevice((e)->device)); stage_reset(e); (e)->hdr_fresh = false; } while (0)
+// A wait on a peer window that gave up leaves its level partly applied (the regions of the sources that had arrived went in): the
+// worker-loop calls refuse from then on, until ocrgpu_restore puts a snapshot back or ocrgpu_peer_connect joins fresh windows (the
+// caller then vouches for the state).
+#define REFUSE_POISONED(e) do { if ((e)->poisoned) FAIL(OCRGPU_EHIP, "a wait on a peer window gave up earlier and left its level partly applied: ocrgpu_restore a snapshot " \
+                                                                    "(or join fresh windows with ocrgpu_peer_connect) before going on"); } while (0)
 
 // ---- CSR seal ---------------------------------------------------------------------------------------------
 static int seal(ocrgpu_engine *e) {
@@ -3545,6 +3551,7 @@ static int run_async(ocrgpu_engine *e) {
 }
 extern "C" int ocrgpu_resolve(ocrgpu_engine_t *e, u64 max_levels, ocrgpu_stats_t *stats_out) {
     ENTER(e);
+    REFUSE_POISONED(e);
     u64 max_launches = max_levels ? 4 * max_levels + 64 : ~0ull;
     int r;
     bool done = false;
@@ -3570,6 +3577,7 @@ extern "C" int ocrgpu_resolve(ocrgpu_engine_t *e, u64 max_levels, ocrgpu_stats_t
 extern "C" int ocrgpu_step(ocrgpu_engine_t *e, u32 fire_levels, u32 flags, u64 *has_ready_out, u64 *pending_records_out,
                            u32 *send_counts_out) {
     ENTER(e);
+    REFUSE_POISONED(e);
     // one run: close pending satisfies, fire at most `fire_levels` levels (an empty one if forced), close again;
     // 3 launches cover the common single-level case (FIRE, the no-op that notices quiescence, one spare)
     int r = run_steps(e, fire_levels, ~0ull, true, flags & (OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_DROP_EMPTY_LEVEL), fire_levels == 1 ? 3u : 2u);
@@ -3602,6 +3610,7 @@ static int pop_ready_into(ocrgpu_engine *e, char *buf, u32 r_end, u64 max_edts, 
     HIPCHK(hipMemsetAsync(cnt, 0, 256, e->stream)); // the buffer keeps the last call's contents: the two counters start at zero
     u64 span = r_end - e->pop_cursor; u32 g = nblk(span); if (g > 4096) g = 4096;
     k_pop_ready<<<g, 256, 0, e->stream>>>(e->d, e->pop_cursor, r_end, (u32)max_edts, (u32)max_deps, cnt, dp0, ddc, ddf, dgd, dvl);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(e->pinned_done + 33012, cnt, 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     const u64 ne = e->pinned_done[33012], nd = e->pinned_done[33013];
@@ -3655,6 +3664,7 @@ extern "C" int ocrgpu_pop_ready(ocrgpu_engine_t *e, u64 max_edts, u64 max_deps, 
 static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
 #define NOALLOC_MAX_DEVICES 64
 static unsigned char *g_scratch_ptr[NOALLOC_MAX_DEVICES]; // device address of `scratch` on each GPU (hipGetSymbolAddress), 0 = not asked yet
+static std::atomic<int> g_scratch_busy[NOALLOC_MAX_DEVICES];
 static int scratch_setup(int device) { // called by ocrgpu_init with `device` current
     if (device < 0 || device >= NOALLOC_MAX_DEVICES) return 0; // such a device has no no-alloc entry point (it says so when called)
     if (g_scratch_ptr[device]) return 0;
@@ -3672,6 +3682,9 @@ extern "C" int ocrgpu_pop_ready_noalloc(ocrgpu_engine_t *e, u64 max_edts, u64 ma
              (unsigned long long)max_edts, (unsigned long long)max_deps, NOALLOC_MAX_EDTS, NOALLOC_MAX_DEPS);
     unsigned char *ptr = (e->device >= 0 && e->device < NOALLOC_MAX_DEVICES) ? g_scratch_ptr[e->device] : nullptr;
     if (!ptr) FAIL(OCRGPU_ENOTSUP, "ocrgpu_pop_ready_noalloc: no scratch address for device %d", e->device);
+    // every engine on this GPU shares the one array: a call that overlaps another one (two threads, two engines) is refused, not raced
+    struct Busy { std::atomic<int> &f; bool mine; Busy(std::atomic<int> &x) : f(x), mine(x.exchange(1) == 0) {} ~Busy() { if (mine) f.store(0); } } busy(g_scratch_busy[e->device]);
+    if (!busy.mine) FAIL(OCRGPU_EINVAL, "ocrgpu_pop_ready_noalloc: another call is using device %d's scratch array (calls on one GPU must not overlap)", e->device);
     u32 r_end;
     int r = pop_ready_args(e, max_edts, max_deps, n_edts_out, n_deps_out, param0_out, depc_out, dep_first_out, dep_guid_out, dep_value_out, &r_end);
     if (r) return r;
@@ -3950,7 +3963,7 @@ extern "C" int ocrgpu_peer_connect(ocrgpu_engine_t *e, const void *handles) {
     e->peer_limit = 100000ull * (u64)(ms && atoi(ms) > 0 ? atoi(ms) : 2000); // 100 MHz ticks
     const char *pf = getenv("OCRGPU_PEER_FENCE");
     e->peer_fence_wave = pf && !strcmp(pf, "wave") ? 1u : 0u;
-    e->peer_opened.swap(opened); e->peer_round = 0; e->peer_on = true;
+    e->peer_opened.swap(opened); e->peer_round = 0; e->peer_on = true; e->poisoned = false;
     return 0;
 }
 extern "C" int ocrgpu_peer_fini(ocrgpu_engine_t *e) {
@@ -3981,14 +3994,16 @@ static int peer_exchange(ocrgpu_engine **g, u32 n, u64 *h, bool ahead = false, u
         const SendRec *recs = (const SendRec *)(e->peer_win + peer_regions_off(d.n_loc)) + (size_t)(e->peer_round & 1) * d.n_loc * d.send_cap;
         int r = xchg_land(e, recs, true, h, ahead, no_cascade, next_K0 ? e->launch_index + 1 : 0u); if (r) return r;
         e->peer_round++;
-        if (!ahead && e->pinned_done[PIN_PEER_LATE]) FAIL(OCRGPU_EHIP, "peer windows: %u of %u partitions did not arrive at location %u within the limit (OCRGPU_PEER_TIMEOUT_MS); "
-                                               "the round was not applied and the run cannot continue", e->pinned_done[PIN_PEER_LATE], d.n_loc, e->cfg.location);
+        if (!ahead && e->pinned_done[PIN_PEER_LATE]) { e->poisoned = true;
+                                               FAIL(OCRGPU_EHIP, "peer windows: %u of %u partitions did not arrive at location %u within the limit (OCRGPU_PEER_TIMEOUT_MS); "
+                                               "the round may be partly applied and the run cannot continue", e->pinned_done[PIN_PEER_LATE], d.n_loc, e->cfg.location); }
     }
     return 0;
 }
 extern "C" int ocrgpu_exchange(ocrgpu_engine_t *e, u64 *records_in_out, u64 *activity_out, u64 *sent_out, u64 *queued_out) {
     const bool fresh = e && e->hdr_fresh;
     ENTER(e);
+    REFUSE_POISONED(e);
     if (!e->comm && !e->peer_on) FAIL(OCRGPU_EINVAL, "no transport (ocrgpu_comm_init or ocrgpu_peer_connect)");
     u64 h[4]; int r;
     if (e->peer_on) { if ((r = peer_exchange(&e, 1, h))) return r; }
@@ -4154,8 +4169,9 @@ static int resolve_run_ahead(ocrgpu_engine **g, u32 n, u32 flags, u64 *levels_ou
     for (u32 i = 0; i < n; ++i) { HIPCHK(hipSetDevice(g[i]->device)); HIPCHK(hipStreamSynchronize(g[i]->stream)); }
     for (u32 i = 0; i < n; ++i) {
         ocrgpu_engine *e = g[i];
-        if (e->pinned_done[PIN_PEER_LATE]) FAIL(OCRGPU_EHIP, "peer windows: %u of %u partitions did not arrive at location %u within the limit (OCRGPU_PEER_TIMEOUT_MS); "
-                                               "the run cannot continue", e->pinned_done[PIN_PEER_LATE], e->d.n_loc, e->cfg.location);
+        if (e->pinned_done[PIN_PEER_LATE]) { e->poisoned = true;
+                                               FAIL(OCRGPU_EHIP, "peer windows: %u of %u partitions did not arrive at location %u within the limit (OCRGPU_PEER_TIMEOUT_MS); "
+                                               "the run cannot continue", e->pinned_done[PIN_PEER_LATE], e->d.n_loc, e->cfg.location); }
         if (!e->pinned_done[PIN_RA]) FAIL(OCRGPU_EHIP, "rounds queued ahead ended without the stop word at location %u", e->cfg.location);
         if (e->pinned_done[PIN_RA + 2] == 0xBAD0BAD0u) FAIL(OCRGPU_EINVAL, "OCRGPU_RX_NO_CASCADE: a partition had not fired its level when the others' records of that level arrived "
                                                                             "(its launches went into what the arrivals of the level before set off); the run was stopped. Resolve without "
@@ -4196,6 +4212,7 @@ static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags
 }
 extern "C" int ocrgpu_resolve_exchange(ocrgpu_engine_t *e, u32 flags, u64 *levels_out) {
     if (!e) FAIL(OCRGPU_EINVAL, "null engine");
+    REFUSE_POISONED(e);
     if (!e->comm && !e->peer_on) FAIL(OCRGPU_EINVAL, "no transport (ocrgpu_comm_init or ocrgpu_peer_connect)");
     return resolve_exchange_group(&e, 1, true, flags, levels_out);
 }
@@ -4315,6 +4332,7 @@ extern "C" int ocrgpu_restore(ocrgpu_engine_t *e) {
     Dev &d = e->d; Snapshot &s = e->snap;
     if (!s.valid) FAIL(OCRGPU_EINVAL, "no snapshot taken");
     if (s.n_edt != e->n_edt || s.n_evt != e->n_evt || s.mut_epoch != e->mut_epoch) FAIL(OCRGPU_EINVAL, "objects were created or reclaimed after the snapshot");
+    e->poisoned = false; // (the snapshot's state replaces whatever a round that gave up left half applied)
     e->pop_cursor = e->snap_pop_cursor;
     e->n_db = s.n_db; // (proxy datablocks cloned from other partitions since the snapshot go with Ctrl.proxy_used)
     // the registration log is append-only and Ctrl.log_tail goes back with Ctrl: what was registered since the snapshot is

@@ -177,6 +177,11 @@ def test_a_partition_that_does_not_arrive_fails_the_round(monkeypatch):
     D.connect_peer_windows(parts)
     with pytest.raises(E.OcrGpuError, match="did not arrive"):
         parts[0].eng.exchange()
+    # the level may be partly applied: the worker-loop calls refuse until a snapshot is restored or fresh windows are joined
+    for call in (lambda: parts[0].eng.step(1), lambda: parts[0].eng.exchange(), lambda: parts[0].eng.resolve()):
+        with pytest.raises(E.OcrGpuError, match="gave up earlier"):
+            call()
+    parts[1].eng.step(1)                   # the partition that did not wait is not affected
     for p in parts:
         p.eng.close()
 

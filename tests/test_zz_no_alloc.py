@@ -40,13 +40,17 @@ def _drive(eng, n, first_handle, rng_seed):
 def test_noalloc_matches_pop_ready_on_two_calls_in_a_row():
     a = E.Engine(max_edt=8192, max_evt=4, max_db=256, max_slots=40000, max_edges=40000)
     b = E.Engine(max_edt=8192, max_evt=4, max_db=256, max_slots=40000, max_edges=40000)
+    import torch
     for n, first, seed in ((5000, 0, 11), (700, 100000, 12)):       # the second call is the smaller one
         _drive(a, n, first, seed)
         _drive(b, n, first, seed)
         want = _records(*a.pop_ready())
+        b.sync()
+        free_before = torch.cuda.mem_get_info(0)[0]                 # hipMemGetInfo: the contract in the name
         got = _records(*b.pop_ready_noalloc())
         assert len(want) == n and got == want
         assert len(b.pop_ready_noalloc()[0]) == 0                   # nothing is handed over twice
+        assert torch.cuda.mem_get_info(0)[0] == free_before, "ocrgpu_pop_ready_noalloc changed the device's free memory"
     assert sum(a.stats().err) == 0 and sum(b.stats().err) == 0
     a.close()
     b.close()
