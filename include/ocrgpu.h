@@ -101,10 +101,20 @@ typedef struct {
                                  * its ocrAddDependence named (DB_MODE_CONST / RW / EW / RO), waits in line on a busy one
                                  * and only then becomes ready; the level that fires it releases them (iterateDbFrontier
                                  * hc-task.c:484-544, lockableAcquireInternal / lockableRelease
-                                 * lockable-datablock.c:139-263, 330-507).  One partition only (no exchange); at most
-                                 * 4096 pre-slots per EDT (a larger ocrgpu_edt_create entry is a malformed op).  Which of
-                                 * several contenders gets a datablock first is a race, as it is between the reference's
-                                 * workers; everything but the levels of the contenders is deterministic.             */
+                                 * lockable-datablock.c:139-263, 330-507).  At most 4096 pre-slots per EDT (a larger
+                                 * ocrgpu_edt_create entry is a malformed op).  Which of several contenders gets a datablock
+                                 * first is a race, as it is between the reference's workers; everything but the levels of
+                                 * the contenders is deterministic.
+                                 * Across partitions (ocrgpu_exchange_config) a datablock made by ocrgpu_db_create is arbitrated
+                                 * by the partition that made it, as under hc-dist (the acquire / release messages go to the
+                                 * owner's policy domain, hc-dist-policy.c:1027-1031): a satisfy that carries such a datablock
+                                 * takes 2 slots of its send region (the second names the original), an EDT whose next
+                                 * datablock -- in ascending guid order, one order everywhere -- is a copy asks the owner with
+                                 * a record and goes on when the grant arrives, the level that fires it sends the releases.
+                                 * Grants and releases are records that set off records: not with OCRGPU_RX_NO_CASCADE, rounds
+                                 * are driven by the host (never queued ahead), ocrgpu_snapshot is refused.  The output
+                                 * datablock of an EDT that travels to another partition is a private copy there (arbitrated
+                                 * where the copy lives).                                                                 */
 
 typedef struct {
     uint64_t levels;        /* topological levels run by the last resolve                      */

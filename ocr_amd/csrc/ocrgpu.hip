@@ -116,6 +116,16 @@ static_assert(sizeof(SendRec) == 32, "SendRec is 32 bytes");
 #define XF_TILE_WB 256u  // head (with XF_HAS_TILE): guid = a datablock HERE; a TILE body updated a copy of it elsewhere and its contents come
                          // home (the write-back of a released RW / EW proxy, hc-dist-policy.c PD_MSG_DB_RELEASE); satisfies nothing
 #define TILE_REC_SLOTS 23u
+// Lockable datablocks (OCRGPU_F_LOCKABLE_DB) across partitions: a datablock is arbitrated WHERE IT LIVES (lockable-datablock.c:139-263,
+// 330-507 run on the owner's policy domain; hc-dist forwards PD_MSG_DB_ACQUIRE / DB_RELEASE there, hc-dist-policy.c:1027-1031).
+#define XF_HAS_HOME 512u   // head + ONE continuation slot whose guid field is the guid the datablock was created under: a copy stays tied to
+                           // the original, whose owner arbitrates every access to it
+#define XF_ACQ 1024u       // guid = a datablock HERE, slot = access mode, value = requester (location << 32 | EDT index): acquire, or wait in line
+#define XF_GRANT 2048u     // value = EDT index HERE: the datablock it asked another partition for is now its: it goes on acquiring
+#define XF_REL 4096u       // guid = a datablock HERE: one remote holder is done with it
+#define XF_ACQMODE_SHIFT 16u // bits 16..19 of the flags of a satisfy for an EDT pre-slot: the access mode its ocrAddDependence named
+#define HOME_REC_SLOTS 2u
+struct RWait { u32 loc, edt, next, pad; }; // a requester on another partition waiting in a datablock's line (list entries above max_edt name these)
 #define RF_REMOTE 8u     // waiter flag (with bit0 clear): lo = index into rdst[]; bit2 = dst is an EDT, bit1 = MODE_NULL
 struct RemoteDst { u64 guid; u32 slot, flags; };
 
@@ -149,9 +159,11 @@ struct alignas(128) Ctrl {
     DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB only (else null): lock word + waiter lists per datablock; access mode per
                                           // EDT pre-slot.  Kept here, not in Dev: the hot kernel's argument block stays as small as it was
     u64 *tiles;                 // OCRGPU_F_WIDE_DB only (else null): the 8x8 tile of 64-bit integers behind datablock i at tiles[64 * i]
-    u64 *db_home;               // OCRGPU_F_WIDE_DB only: the guid datablock i was created under -- its own, or for a copy that a record
-                                // brought in (a proxy) the guid of the original on its home partition
-    u32 pad5[16];
+    u64 *db_home;               // OCRGPU_F_WIDE_DB / _LOCKABLE_DB: the guid datablock i was created under -- its own, or for a copy that a
+                                // record brought in (a proxy) the guid of the original on its home partition
+    RWait *rwait; u64 *rrel;    // OCRGPU_F_LOCKABLE_DB with partitions: remote requesters in line; releases that arrived this round (guids)
+    u32 rwait_cap, rwait_used, rrel_cap, rrel_n;
+    u32 pad5[8];
     // during a run
     State state[2];
     Cnt cnt_r[3], cnt_q[3];     // launch K appends through cnt_*[K%3]; launch K+1 reads them; launch K zeroes [(K+1)%3]
@@ -515,8 +527,27 @@ __device__ __forceinline__ void lazy_walk(const Dev &d, u32 edt, u32 slot) {
 __device__ __forceinline__ size_t acq_index(const Dev &d, u32 edt, u32 depc, u32 ovf_base, u32 slot) {
     return depc <= INLINE_SLOTS ? (size_t)edt * INLINE_SLOTS + slot : (size_t)d.max_edt * INLINE_SLOTS + ovf_base + slot;
 }
-// true = acquired; false = OCR_EBUSY: queued on the list of its mode (push-front like the reference's lists)
-__device__ __forceinline__ bool db_acquire(const Dev &d, u32 db, u32 mode, u32 e) {
+// Who stands in a datablock's line: a list entry w <= max_edt is local EDT w - 1 (its link to the next entry sits in the upper half of
+// its `val`), a larger one is remote requester rwait[w - max_edt - 1] (a partition that asked with an XF_ACQ record).
+__device__ __forceinline__ u32 *waiter_link(const Dev &d, u32 w) {
+    return w <= d.max_edt ? reinterpret_cast<u32 *>(&d.edt[w - 1u].val) + 1 : &d.ctrl->rwait[w - d.max_edt - 1u].next;
+}
+// The order in which an EDT takes its datablocks must be ONE order for everybody who can meet on them (sortRegNode, hc-task.c:459-477:
+// ascending guid).  A datablock made by ocrgpu_db_create -- or a copy of one that came in a record -- goes by the guid it was created
+// under, which is the same on every partition; the output datablock of an EDT is only ever contended where it lives and goes by its
+// index there, behind all the others.
+__device__ __forceinline__ u64 acq_key(const Dev &d, u32 p /* index + 1 */) {
+    if (p - 1u < d.max_db) { const u64 g = d.ctrl->db_home ? d.ctrl->db_home[p - 1u] : 0ull; return g ? (g & 0x7FFFFFFFFFFFFFFFull) : (u64)p; }
+    return 0x8000000000000000ull | p;
+}
+// the partition that arbitrates datablock p (this one unless p is a copy of another partition's datablock)
+__device__ __forceinline__ u64 acq_remote_home(const Dev &d, u32 p) {
+    if (d.n_loc <= 1 || p - 1u >= d.max_db || !d.ctrl->db_home) return 0ull;
+    const u64 g = d.ctrl->db_home[p - 1u];
+    return (g && OCRGPU_GUID_LOCATION(g) != d.location) ? g : 0ull;
+}
+// true = acquired; false = OCR_EBUSY: queued on the list of its mode (push-front like the reference's lists).  `who` = list entry
+__device__ __forceinline__ bool db_acquire(const Dev &d, u32 db, u32 mode, u32 who) {
     DbLock *B = &d.ctrl->dbl[db];
     u32 o = atomicAdd(&B->state, 0u);
     for (;;) {
@@ -529,29 +560,36 @@ __device__ __forceinline__ bool db_acquire(const Dev &d, u32 db, u32 mode, u32 e
             else if (o) list = &B->itw;
             else nw = (DBL_ITW << 30) | 1u;
         }
-        if (list) { reinterpret_cast<u32 *>(&d.edt[e].val)[1] = atomicExch(list, e + 1u); return false; }
+        if (list) { *waiter_link(d, who) = atomicExch(list, who); return false; }
         const u32 prev = atomicCAS(&B->state, o, nw);
         if (prev == o) return true;
         o = prev;
     }
 }
-// iterateDbFrontier: go on from the last datablock taken (lower half of `val`); true = holds them all -> scheduleTask
+// iterateDbFrontier: go on from the last datablock taken (lower half of `val`: 1 + the pre-slot that named it); true = holds them all
+// -> scheduleTask.  A datablock another partition arbitrates is asked for with a record (XF_ACQ); the EDT goes on when the grant arrives.
+template <bool XL> // XL: datablocks may live on other partitions (compiled out of the one-partition kernels: tests/test_kernel_resources.py)
 __device__ __forceinline__ bool acq_walk(const Dev &d, u32 e) {
     EdtLine *L = &d.edt[e];
     const u32 depc = L->depc;
     const u32 *sl = depc <= INLINE_SLOTS ? L->slot : d.slots + L->slot[0];
     const unsigned char *md = d.ctrl->acq_mode + acq_index(d, e, depc, L->slot[0], 0u);
-    u32 last = (u32)L->val;
+    const u32 lk = (u32)L->val;
+    u64 last = lk ? acq_key(d, sl[lk - 1u] & 0x7FFFFFFFu) : 0ull;
     for (;;) {
-        u32 best = 0xFFFFFFFFu, bm = 0; // the next datablock in ascending order; named twice = the mode of its lowest pre-slot (stable sort :459-477)
-        for (u32 k = 0; k < depc; ++k) { const u32 p = sl[k] & 0x7FFFFFFFu; if (p > last && p < best) { best = p; bm = md[k]; } }
-        if (best == 0xFFFFFFFFu) { L->val = 0; return true; }
+        u64 best = ~0ull; u32 bk = 0; // the next datablock in ascending order; named twice = the mode of its lowest pre-slot (stable sort :459-477)
+        for (u32 k = 0; k < depc; ++k) { const u32 p = sl[k] & 0x7FFFFFFFu; if (!p) continue; const u64 key = acq_key(d, p); if (key > last && key < best) { best = key; bk = k; } }
+        if (best == ~0ull) { L->val = 0; return true; }
         last = best;
-        reinterpret_cast<u32 *>(&L->val)[0] = last; // moved on before the attempt, like frontierSlot (:491)
-        if (!db_acquire(d, best - 1u, bm, e)) return false;
+        reinterpret_cast<u32 *>(&L->val)[0] = bk + 1u; // moved on before the attempt, like frontierSlot (:491)
+        const u32 p = sl[bk] & 0x7FFFFFFFu;
+        const u64 home = XL ? acq_remote_home(d, p) : 0ull;
+        if (XL && home) { emit_remote_raw(d, home, md[bk], XF_ACQ, ((u64)d.location << 32) | e, 0ull); return false; } // its owner answers with XF_GRANT
+        if (!db_acquire(d, p - 1u, md[bk], e + 1u)) return false;
     }
 }
-// lockableRelease: `push(edt)` queues an RF_ACQUIRE record for every waiter the datablock is handed to
+// lockableRelease: `push(w)` is called for every list entry the datablock is handed to (a local EDT goes on acquiring, a remote
+// requester gets its grant)
 template <class Push>
 __device__ __forceinline__ void db_release(const Dev &d, u32 db, Push push) {
     DbLock *B = &d.ctrl->dbl[db];
@@ -565,23 +603,32 @@ __device__ __forceinline__ void db_release(const Dev &d, u32 db, Push push) {
         w = atomicExch(&B->itw, 0u);                             // every RW waiter of the location (:390-438)
         if (w) lock = DBL_ITW;
         else if ((w = atomicAdd(&B->ew, 0u)) != 0u) {            // one EW waiter (:393-395, 439-458)
-            atomicExch(&B->ew, reinterpret_cast<u32 *>(&d.edt[w - 1u].val)[1]);
-            push(w - 1u);
+            atomicExch(&B->ew, *waiter_link(d, w));
+            push(w);
             atomicExch(&B->state, (DBL_EW << 30) | 1u);
             return;
         }
     }
-    for (; w; w = reinterpret_cast<u32 *>(&d.edt[w - 1u].val)[1]) { ++n; push(w - 1u); }
+    for (; w; w = *waiter_link(d, w)) { ++n; push(w); }
     atomicExch(&B->state, (lock << 30) | n);
 }
-template <class Push>
+// what `push` does with a remote list entry: the grant goes back to the partition that asked
+__device__ __forceinline__ void grant_remote(const Dev &d, u32 w) {
+    const RWait r = d.ctrl->rwait[w - d.max_edt - 1u];
+    emit_remote_raw(d, mkguid(r.loc, OCRGPU_KIND_EDT, 1ull), 0u, XF_GRANT, (u64)r.edt, 0ull);
+}
+template <bool XL, class Push>
 __device__ __forceinline__ void release_all(const Dev &d, const u32 *sl, u32 depc, Push push) { // the epilogue's release loop
     for (u32 k = 0; k < depc; ++k) {
         const u32 p = sl[k] & 0x7FFFFFFFu;
         if (!p) continue;
+        const u64 key = acq_key(d, p);
         bool dup = false;
-        for (u32 j = 0; j < k; ++j) dup |= (sl[j] & 0x7FFFFFFFu) == p;
-        if (!dup) db_release(d, p - 1u, push);
+        for (u32 j = 0; j < k; ++j) { const u32 q = sl[j] & 0x7FFFFFFFu; dup |= q != 0u && acq_key(d, q) == key; }
+        if (dup) continue;
+        const u64 home = XL ? acq_remote_home(d, p) : 0ull;
+        if (XL && home) emit_remote_raw(d, home, 0u, XF_REL, 0ull, 0ull); // its owner takes this holder off (lockableRelease runs there)
+        else db_release(d, p - 1u, push);
     }
 }
 
@@ -720,6 +767,16 @@ __device__ void emit_remote_tile(const Dev &d, u64 guid, u32 slot, u32 xflags, u
 }
 // XT: the caller may meet tile datablocks that cross partitions (compiled out of the k_step instantiations that cannot: the code costs
 // the tile-body kernel a wave of occupancy and spills; tests/test_kernel_resources.py holds the one-partition kernels to what they had)
+// a record that carries a datablock of a Lockable engine: the guid it was created under rides in ONE continuation slot (XF_HAS_HOME)
+__device__ void emit_remote_home(const Dev &d, u64 guid, u32 slot, u32 xflags, ulonglong2 b, u32 dbi) {
+    const u32 loc = OCRGPU_GUID_LOCATION(guid);
+    if (d.send == nullptr || loc >= d.n_loc) { atomicAdd(&d.ctrl->err[ERR_BAD_OP], 1u); return; }
+    const u32 pos = atomicAdd(&d.send_cnt[loc * 32], HOME_REC_SLOTS);
+    if ((u64)pos + HOME_REC_SLOTS + 1 > d.send_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+    SendRec *r = d.send + (size_t)loc * d.send_cap + pos;
+    r[0] = SendRec{guid, slot, xflags | XF_HAS_DB | XF_HAS_HOME, b.x, b.y};
+    r[1] = SendRec{d.ctrl->db_home[dbi], 0u, XF_CONT, 0ull, 0ull};
+}
 template <bool AGG = false, bool XT = true>
 __device__ __forceinline__ void emit_remote(const Dev &d, u64 guid, u32 slot, u32 xflags, u32 payload) {
     u32 loc = OCRGPU_GUID_LOCATION(guid);
@@ -727,7 +784,10 @@ __device__ __forceinline__ void emit_remote(const Dev &d, u64 guid, u32 slot, u3
     ulonglong2 b = make_ulonglong2(0, 0);
     if (payload && !(xflags & XF_MODE_NULL)) { b = db_gather(d, payload); xflags |= XF_HAS_DB; }
     if (XT && !AGG) { // (the wavefront-aggregated form is the fan-out of the engines WITHOUT tile datablocks)
-        if ((xflags & XF_HAS_DB) && payload - 1 < d.max_db && d.ctrl->tiles) { emit_remote_tile(d, guid, slot, xflags, b, payload - 1); return; }
+        if ((xflags & XF_HAS_DB) && payload - 1 < d.max_db) {
+            if (d.ctrl->tiles) { emit_remote_tile(d, guid, slot, xflags, b, payload - 1); return; }
+            if (d.ctrl->dbl) { emit_remote_home(d, guid, slot, xflags, b, payload - 1); return; }
+        }
     }
     emit_remote_record<AGG>(d, guid, slot, xflags, b.x, b.y);
 }
@@ -769,7 +829,7 @@ __device__ __forceinline__ void emit_remote_record(const Dev &d, u64 guid, u32 s
 // consecutive entries of the ready log up front (one atomic, issued before the waiter loads so it costs no
 // extra round trip) and lane t writes entry t: the EDT it made ready, or INVALID.  Compaction happens on
 // the read side (the FIRE pass skips holes), where it is a ballot instead of a dependent atomic.
-template <bool NANNY, bool LOCKABLE, int TILES>
+template <bool NANNY, int LOCKABLE, int TILES>
 __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 total, u32 *lds_base, u64 &n_edt_sat, u64 &n_evt_sat) {
     Ctrl *c = d.ctrl;
     u32 rbase = 0;
@@ -798,8 +858,8 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         bool l_lead = false; s32 l_old = 0, l_delta = 0;
         if (__ballot(is_latch)) latch_issue(d, is_latch, dst, slot, l_lead, l_old, l_delta);
         if (act) {
-            if (flags & RF_DST_EDT) ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, dst, slot, payload, flags);
-            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote<TILES == 0, TILES == 2>(d, rd.guid, rd.slot, rd.flags, payload); }
+            if (flags & RF_DST_EDT) ready = edt_slot_satisfy<NANNY, LOCKABLE != 0>(d, S, dst, slot, payload, flags);
+            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote<TILES == 0 && LOCKABLE != 2, TILES == 2 || LOCKABLE == 2>(d, rd.guid, rd.slot, rd.flags, payload); }
         }
         // statistics are wave totals (one ballot each), so the epilogue needs no cross-lane reduction
         n_edt_sat += __popcll(__ballot(act && (flags & RF_DST_EDT))); n_evt_sat += __popcll(__ballot(to_evt));
@@ -976,7 +1036,7 @@ __device__ void deferred_bodies(const Dev &d, u32 b_begin, u32 b_end, u32 h, u32
 // One launch = one phase.  K is the launch index (host counter): it selects the state / counter buffers.
 // TILES (OCRGPU_F_WIDE_DB): OCRBODY_TILE bodies are compiled in -- a variant of its own, so that the default kernel keeps
 // its registers (118 VGPRs, 4 waves per SIMD; with the tile code inline: 137 and 3).
-template <bool NANNY, bool LOCKABLE, int TILES>
+template <bool NANNY, int LOCKABLE, int TILES>
 __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #ifdef OCRGPU_STAMPS
     u64 _t0 = __builtin_amdgcn_s_memrealtime();
@@ -1124,7 +1184,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                             u32 pay = pk == OCRGPU_PAY_GUID ? sc.payload : pk == OCRGPU_PAY_OUTDB ? d.max_db + e + 1
                                     : pk == OCRGPU_PAY_DEPV ? (sl[sc.payload] & 0x7FFFFFFFu) : 0u;
                             if (sc.op_kind & 0x10000u) { // the event lives on another partition
-                                RemoteDst rd = d.rdst[sc.target]; emit_remote<false, TILES == 2>(d, rd.guid, rd.slot, 0u, pay); continue;
+                                RemoteDst rd = d.rdst[sc.target]; emit_remote<false, TILES == 2 || LOCKABLE == 2>(d, rd.guid, rd.slot, 0u, pay); continue;
                             }
                             u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
                             if (qi < d.q_cap) d.q[qi] = Rec{sc.target, pay, sc.slot, 0u};
@@ -1138,9 +1198,10 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                     }
                 }
                 if (LOCKABLE && depc && !host_body) // Lockable datablocks: the body has run, its datablocks go back (host bodies: ocrgpu_edt_release_dbs)
-                    release_all(d, sl, depc, [&](u32 w) {
+                    release_all<LOCKABLE == 2>(d, sl, depc, [&](u32 w) {
+                        if (LOCKABLE == 2 && w > d.max_edt) { grant_remote(d, w); return; } // a requester on another partition is next in line
                         const u32 qi = S.q_base + atomicAdd(S.cnt_q, 1u);
-                        if (qi < d.q_cap) d.q[qi] = Rec{w, 0u, 0u, RF_ACQUIRE}; else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
+                        if (qi < d.q_cap) d.q[qi] = Rec{w - 1u, 0u, 0u, RF_ACQUIRE}; else atomicAdd(&c->err[ERR_Q_OVERFLOW], 1u);
                     });
                 if ((body & OCRBODY_F_OUTEVT) && !host_body) { // epilogue: satisfy the ONCE output event with the returned guid
                     epi = true;
@@ -1189,8 +1250,8 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             if (act) {
                 r = d.q[i];
                 if (r.flags & RF_LAZYWALK) lazy_walk(d, r.dst, r.slot);
-                else if (LOCKABLE && (r.flags & RF_ACQUIRE)) ready = acq_walk(d, r.dst);
-                else if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY, LOCKABLE>(d, S, r.dst, r.slot, r.payload, r.flags); cnt_edt = true; }
+                else if (LOCKABLE && (r.flags & RF_ACQUIRE)) ready = acq_walk<LOCKABLE == 2>(d, r.dst);
+                else if (r.flags & RF_DST_EDT) { ready = edt_slot_satisfy<NANNY, LOCKABLE != 0>(d, S, r.dst, r.slot, r.payload, r.flags); cnt_edt = true; }
                 else if (!(r.flags & RF_FIRED)) { kind = (*evt_state(d, r.dst) >> 8) & 0xFF; is_latch = (kind == OCREVT_LATCH); cnt_evt = true; }
             }
             n_edt_sat += __popcll(__ballot(cnt_edt)); n_evt_sat += __popcll(__ballot(cnt_evt));
@@ -1974,8 +2035,8 @@ __device__ bool add_dep_one(const Dev &d, u64 i, const u64 *src, const u64 *dst,
         const u32 dk = OCRGPU_GUID_KIND(dg);
         const bool r_edt = dk == OCRGPU_KIND_EDT;
         if (!r_edt && !is_event_kind(dk)) { bad_op(d); return false; }
-        const u32 xf = (r_edt && mode[i] == OCRMODE_NULL) ? XF_MODE_NULL : 0u;
-        if (s == OCRGPU_NULL_GUID) { emit_remote(d, dg, slot[i], xf, 0u); return false; }
+        const u32 xf = ((r_edt && mode[i] == OCRMODE_NULL) ? XF_MODE_NULL : 0u) | (r_edt ? (mode[i] & 0xFu) << XF_ACQMODE_SHIFT : 0u); // (the mode travels: Lockable datablocks)
+        if (s == OCRGPU_NULL_GUID) { emit_remote(d, dg, slot[i], xf & ~(0xFu << XF_ACQMODE_SHIFT), 0u); return false; }
         u64 sv = gtab_get(d, s); u32 sk = OCRGPU_GUID_KIND(s);
         if (!sv) { atomicAdd(&d.ctrl->err[is_event_kind(sk) ? ERR_LATE_WAITER : ERR_BAD_OP], 1u); return false; }
         if (sk == OCRGPU_KIND_DB) { emit_remote(d, dg, slot[i], xf, (u32)sv); return false; }
@@ -2216,6 +2277,23 @@ __device__ void apply_record(const Dev &d, const SendRec *rp, u32 avail, u32 db_
         tile_from_record(d, rp, (u32)(v - 1));
         return;
     }
+    if (r.flags & (XF_ACQ | XF_REL | XF_GRANT)) { // Lockable datablocks: this partition arbitrates the datablock named (ACQ / REL), or asked for one (GRANT)
+        if (!d.ctrl->dbl) { bad_op(d); return; }
+        if (r.flags & XF_GRANT) { if (r.value >= d.max_edt) { bad_op(d); return; } q_push(d, Rec{(u32)r.value, 0u, 0u, RF_ACQUIRE}); return; } // the EDT goes on acquiring
+        const u64 v = (OCRGPU_GUID_LOCATION(r.guid) == d.location && OCRGPU_GUID_KIND(r.guid) == OCRGPU_KIND_DB) ? gtab_get(d, r.guid) : 0;
+        if (!v || v - 1 >= d.max_db) { bad_op(d); return; }
+        if (r.flags & XF_REL) { // releases and acquisitions never share a launch (the invariant the lock-free record rests on): noted here,
+            const u32 i = atomicAdd(&d.ctrl->rrel_n, 1u); // done by k_remote_releases right behind this kernel
+            if (i < d.ctrl->rrel_cap) d.ctrl->rrel[i] = v - 1; else atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u);
+            return;
+        }
+        const u32 n = atomicAdd(&d.ctrl->rwait_used, 1u);
+        if (n >= d.ctrl->rwait_cap) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
+        d.ctrl->rwait[n] = RWait{(u32)(r.value >> 32), (u32)r.value, 0u, 0u};
+        if (db_acquire(d, (u32)(v - 1), r.slot, d.max_edt + 1u + n)) grant_remote(d, d.max_edt + 1u + n);
+        return;
+    }
+    if ((r.flags & XF_HAS_HOME) && avail < HOME_REC_SLOTS) { bad_op(d); return; }
     if (r.flags & XF_DESTROY) {
         u64 v = (OCRGPU_GUID_LOCATION(r.guid) == d.location && is_event_kind(OCRGPU_GUID_KIND(r.guid))) ? gtab_get(d, r.guid) : 0;
         if (!v) { bad_op(d); return; }
@@ -2231,17 +2309,19 @@ __device__ void apply_record(const Dev &d, const SendRec *rp, u32 avail, u32 db_
     }
     // (the proxy entry of a record that carries a datablock is reserved in front of the table lookup: the two trips overlap)
     u32 pay = 0;
-    const u64 home = (r.flags & XF_HAS_TILE) ? tile_record_home(rp) : 0ull;
-    if (home && OCRGPU_GUID_LOCATION(home) == d.location) { // one of OUR tile datablocks comes back with what was done to it elsewhere: no copy, the original
+    const u64 home = (r.flags & XF_HAS_TILE) ? tile_record_home(rp) : (r.flags & XF_HAS_HOME) ? rp[1].guid : 0ull;
+    if (home && OCRGPU_GUID_LOCATION(home) == d.location) { // one of OUR datablocks comes back (a tile: with what was done to it elsewhere): no copy, the original
         const u64 v = gtab_get(d, home);
         if (!v || v - 1 >= d.max_db) { bad_op(d); return; }
-        tile_from_record(d, rp, (u32)(v - 1)); pay = (u32)v;
+        if (r.flags & XF_HAS_TILE) tile_from_record(d, rp, (u32)(v - 1));
+        pay = (u32)v;
     } else if ((r.flags & XF_HAS_DB) && !(r.flags & XF_LAZYREG)) { // only a record that carries a datablock takes a proxy entry
         const u32 pi = wave_reserve_one(&d.ctrl->proxy_used);
         if ((u64)pi + 1 + db_floor > d.max_db) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
         const u32 proxy = d.max_db - 1u - pi;
         d.db[proxy] = make_ulonglong2(r.value, r.tag); pay = proxy + 1;
-        if (r.flags & XF_HAS_TILE) { tile_from_record(d, rp, proxy); d.ctrl->db_home[proxy] = home; }
+        if (r.flags & XF_HAS_TILE) tile_from_record(d, rp, proxy);
+        if (d.ctrl->db_home) d.ctrl->db_home[proxy] = home; // (0: the output datablock of an EDT -- contended only where a copy lives)
     }
     u32 didx, dslot, dflag;
     if (OCRGPU_GUID_LOCATION(r.guid) != d.location || !resolve_dst(d, r.guid, r.slot, didx, dflag, dslot)) { bad_op(d); return; }
@@ -2260,8 +2340,18 @@ __device__ void apply_record(const Dev &d, const SendRec *rp, u32 avail, u32 db_
         return;
     }
     if ((dflag & RF_DST_EDT) && (r.flags & XF_MODE_NULL)) dflag |= RF_MODE_NULL;
+    if (d.ctrl->acq_mode && (dflag & RF_DST_EDT) && ((r.flags >> XF_ACQMODE_SHIFT) & 0xFu)) // registerSignalerTaskHc records the mode (hc-task.c:1373): it came with the record
+        d.ctrl->acq_mode[acq_index(d, didx, (dflag & RF_INLINE) ? 0u : INLINE_SLOTS + 1u, d.edt[didx].slot[0], dslot)] = (unsigned char)((r.flags >> XF_ACQMODE_SHIFT) & 0xFu);
     q_push(d, Rec{didx, pay, dslot, dflag});
 }
+// The releases a round brought in (XF_REL), in a launch of their own behind the apply: lockableRelease for each, hand-overs included
+// (a local EDT in line goes on acquiring in the next EVENTS launch, a remote requester gets its grant with the next exchange).
+__global__ void k_remote_releases(Dev d) {
+    const u32 n = d.ctrl->rrel_n < d.ctrl->rrel_cap ? d.ctrl->rrel_n : d.ctrl->rrel_cap;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        db_release(d, (u32)d.ctrl->rrel[i], [&](u32 w) { if (w > d.max_edt) grant_remote(d, w); else q_push(d, Rec{w - 1u, 0u, 0u, RF_ACQUIRE}); });
+}
+__global__ void k_remote_releases_done(Dev d) { d.ctrl->rrel_n = 0; }
 __global__ void k_exchange_apply(Dev d, u64 n, const SendRec *recs, u32 db_floor) {
     u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
     if (i < n) apply_record(d, recs + i, (u32)(n - i > 0xFFFFFFFFull ? 0xFFFFFFFFull : n - i), db_floor);
@@ -2291,6 +2381,7 @@ __device__ __forceinline__ u64 records_sent_block(const Dev &d, unsigned long lo
 __device__ __forceinline__ void header_words(const Dev &d, u32 K, u32 loc, u64 *h, u64 sent) {
     const State *S = &d.ctrl->state[K & 1];
     u32 mine = d.send_cnt[loc * 32]; if (mine > d.send_cap - 1) mine = d.send_cap - 1;
+    d.send_cnt[loc * 32 + 1] = mine; // what this round carries away: exchange_finish keeps what is queued behind it
     // (a step that was launched ahead without a poll may have run out of launches before it was done: that counts as "queued",
     // so that every partition comes back for a settle round)
     // activity = EDTs fired by this step + records sent + "EDTs are ready here" (a partition that caught up late, outside the
@@ -2315,7 +2406,16 @@ __device__ void exchange_finish(const Dev &d, u32 K, u32 n_src, u64 stride, cons
     const u32 t = threadIdx.x;
     if (t < 4) sum[t] = 0;
     __syncthreads();
-    for (u32 l = t; l < d.n_loc; l += blockDim.x) d.send_cnt[l * 32] = 0;
+    // The send regions start over -- behind what THIS round's apply queued in them while it ran (an XF_ACTIVATE answering a lazy
+    // registration, the grant of a Lockable datablock that was free): those records sit behind the ones the round carried away
+    // (send_cnt[+1], noted when the headers were written) and move to the front.  (Setting the counters to zero dropped them.)
+    for (u32 l = t; l < d.n_loc; l += blockDim.x) {
+        u32 cur = d.send_cnt[l * 32]; if (cur > d.send_cap - 1) cur = d.send_cap - 1;
+        const u32 gone = d.send_cnt[l * 32 + 1], keep = cur > gone ? cur - gone : 0u;
+        SendRec *R = d.send + (size_t)l * d.send_cap;
+        for (u32 i = 0; i < keep; ++i) R[i] = R[gone + i];
+        d.send_cnt[l * 32] = keep; d.send_cnt[l * 32 + 1] = 0;
+    }
     for (u32 x = t; x < n_src; x += blockDim.x) {
         const u64 *h = (const u64 *)&recs[(u64)x * stride + (stride - 1)];
         for (u32 k = 0; k < 4; ++k) if (h[k]) atomicAdd(&sum[k], (unsigned long long)h[k]);
@@ -2793,6 +2893,7 @@ struct ocrgpu_engine {
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
     u32 *pinned_done, *pinned_dev; u32 apply_flip; hipEvent_t apply_ev[2]; // the polled page and the device's address of it (k_report)
     DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB: the device tables (the device finds them through Ctrl)
+    RWait *rwait; u64 *rrel;              // OCRGPU_F_LOCKABLE_DB with partitions (through Ctrl as well)
     u64 *tiles, *db_home;                 // OCRGPU_F_WIDE_DB: 64 words per explicit datablock, and the guid each was created under (through Ctrl as well)
     u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
     // comm-platform over RCCL (ocrgpu_comm_*): communicator of this partition, receive regions, a small device word block
@@ -2911,7 +3012,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->seal_epoch = 0; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->snap.dbl = nullptr; e->snap.tiles = nullptr; e->have_events = false;
-    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr; e->dbl = nullptr; e->acq_mode = nullptr; e->tiles = nullptr; e->db_home = nullptr;
+    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr; e->dbl = nullptr; e->acq_mode = nullptr; e->tiles = nullptr; e->db_home = nullptr; e->rwait = nullptr; e->rrel = nullptr;
     e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->pop_cursor = e->snap_pop_cursor = 0; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
     { const char *mp = getenv("OCRGPU_SPREAD_WGS"); u32 v = mp ? (u32)atoi(mp) : 256u; d.spread_wgs = v < 1 ? 1u : (v > MAX_GRID ? (u32)MAX_GRID : v); }
@@ -2953,6 +3054,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&d.db, 16 * (size_t)n_db_total));
     if ((cfg->flags & OCRGPU_F_WIDE_DB) && (cfg->flags & OCRGPU_F_LOCKABLE_DB)) { ocrgpu_fini(e); FAIL(OCRGPU_EINVAL, "OCRGPU_F_WIDE_DB and OCRGPU_F_LOCKABLE_DB cannot be combined"); }
     if (cfg->flags & OCRGPU_F_WIDE_DB) { TRY(dalloc(e, (void **)&e->tiles, 8 * OCROPS_TILE_WORDS * (size_t)cfg->max_db)); TRY(dalloc(e, (void **)&e->db_home, 8 * (size_t)cfg->max_db)); }
+    if ((cfg->flags & OCRGPU_F_LOCKABLE_DB) && !e->db_home) TRY(dalloc(e, (void **)&e->db_home, 8 * (size_t)cfg->max_db));
     if (cfg->flags & OCRGPU_F_LOCKABLE_DB) {
         TRY(dalloc(e, (void **)&e->dbl, sizeof(DbLock) * (size_t)n_db_total));
         TRY(dalloc(e, (void **)&e->acq_mode, (size_t)cfg->max_edt * INLINE_SLOTS + (size_t)d.max_slots));
@@ -3108,10 +3210,11 @@ static int seal(ocrgpu_engine *e) {
 static void launch_step(ocrgpu_engine *e, u32 grid, u32 K) {
     const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
     const Dev &d = e->d;
-    if (e->tiles && d.n_loc > 1) { if (nanny) k_step<true, false, 2><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false, 2><<<grid, BLK, 0, e->stream>>>(d, K); } // tile datablocks that cross partitions
-    else if (e->tiles) { if (nanny) k_step<true, false, 1><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false, 1><<<grid, BLK, 0, e->stream>>>(d, K); }
-    else if (e->dbl) { if (nanny) k_step<true, true, 0><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, true, 0><<<grid, BLK, 0, e->stream>>>(d, K); }
-    else if (nanny) k_step<true, false, 0><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, false, 0><<<grid, BLK, 0, e->stream>>>(d, K);
+    if (e->tiles && d.n_loc > 1) { if (nanny) k_step<true, 0, 2><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, 0, 2><<<grid, BLK, 0, e->stream>>>(d, K); } // tile datablocks that cross partitions
+    else if (e->tiles) { if (nanny) k_step<true, 0, 1><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, 0, 1><<<grid, BLK, 0, e->stream>>>(d, K); }
+    else if (e->dbl && d.n_loc > 1) { if (nanny) k_step<true, 2, 0><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, 2, 0><<<grid, BLK, 0, e->stream>>>(d, K); } // datablocks arbitrated by their owners
+    else if (e->dbl) { if (nanny) k_step<true, 1, 0><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, 1, 0><<<grid, BLK, 0, e->stream>>>(d, K); }
+    else if (nanny) k_step<true, 0, 0><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, 0, 0><<<grid, BLK, 0, e->stream>>>(d, K);
 }
 static int run_steps(ocrgpu_engine *e, u32 allow_fire, u64 max_launches, bool timing, u32 force_level = 0, u32 first_batch = 0) {
     Dev &d = e->d;
@@ -3481,7 +3584,7 @@ __global__ void k_release_dbs(Dev d, u64 n, const u64 *edt) {
     if (!v || OCRGPU_GUID_KIND(edt[i]) != OCRGPU_KIND_EDT) { bad_op(d); return; }
     const EdtLine *L = &d.edt[(u32)(v - 1)];
     const u32 depc = L->depc;
-    release_all(d, depc <= INLINE_SLOTS ? L->slot : d.slots + L->slot[0], depc, [&](u32 w) { q_push(d, Rec{w, 0u, 0u, RF_ACQUIRE}); });
+    release_all<true>(d, depc <= INLINE_SLOTS ? L->slot : d.slots + L->slot[0], depc, [&](u32 w) { if (w > d.max_edt) grant_remote(d, w); else q_push(d, Rec{w - 1u, 0u, 0u, RF_ACQUIRE}); });
 }
 extern "C" int ocrgpu_edt_release_dbs(ocrgpu_engine_t *e, u64 n, const u64 *edt, int where) {
     ENTER(e);
@@ -3703,7 +3806,6 @@ extern "C" int ocrgpu_step_info(ocrgpu_engine_t *e, u64 *out4) {
 //      ocr/src/inc/ocr-comm-platform.h:55-199; the transport itself -- RCCL all-to-all -- is the caller's) ----
 extern "C" int ocrgpu_exchange_config(ocrgpu_engine_t *e, u32 n_locations, void *send_dev_buf, u64 records_per_dest, u64 max_remote_dsts) {
     ENTER(e);
-    if (e->dbl) FAIL(OCRGPU_EINVAL, "OCRGPU_F_LOCKABLE_DB arbitrates within one partition: not with an exchange configured");
     if (n_locations == 0 || n_locations > 1024 || e->cfg.location >= n_locations) FAIL(OCRGPU_EINVAL, "bad n_locations");
     if (n_locations > 1 && (records_per_dest == 0 || records_per_dest > 0xFFFFFFFFull)) FAIL(OCRGPU_EINVAL, "records_per_dest must be in [1, 2^32)");
     Dev &d = e->d;
@@ -3715,7 +3817,21 @@ extern "C" int ocrgpu_exchange_config(ocrgpu_engine_t *e, u32 n_locations, void 
     d.send_cnt = e->send_cnt_dev;
     if (max_remote_dsts && !d.rdst) { int r = dalloc(e, (void **)&d.rdst, sizeof(RemoteDst) * (size_t)max_remote_dsts); if (r) return r; d.rdst_cap = (u32)max_remote_dsts; }
     e->defer_drain = n_locations > 1; // records may target other partitions: the distributed driver steps explicitly
+    if (e->dbl && n_locations > 1 && !e->rwait) { // Lockable datablocks arbitrated by their owners: remote requesters in line, releases of a round
+        const u64 wcap = 4ull * e->cfg.max_edt + 65536ull, rcap = (u64)n_locations * records_per_dest;
+        int r;
+        if ((r = dalloc(e, (void **)&e->rwait, sizeof(RWait) * (size_t)wcap)) || (r = dalloc(e, (void **)&e->rrel, 8 * (size_t)rcap))) return r;
+        struct { RWait *rwait; u64 *rrel; u32 rwait_cap, rwait_used, rrel_cap, rrel_n; } h = {e->rwait, e->rrel, (u32)(wcap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : wcap), 0u, (u32)(rcap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : rcap), 0u};
+        HIPCHK(hipMemcpyAsync(&d.ctrl->rwait, &h, sizeof h, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
     return 0;
+}
+// Lockable datablocks with partitions: the releases the apply kernel noted are done in a launch of their own right behind it
+static void remote_releases(ocrgpu_engine *e) {
+    if (!e->dbl || e->d.n_loc <= 1 || !e->rrel) return;
+    k_remote_releases<<<64, 256, 0, e->stream>>>(e->d);
+    k_remote_releases_done<<<1, 1, 0, e->stream>>>(e->d);
 }
 extern "C" int ocrgpu_exchange_counts(ocrgpu_engine_t *e, u32 *counts_out) {
     ENTER(e);
@@ -3751,6 +3867,7 @@ extern "C" int ocrgpu_exchange_apply_strided(ocrgpu_engine_t *e, const void *rec
     if (n_src > 200) { // beyond the pinned scratch: stage from the vector and wait
         const u32 *dc; if ((r = stage_in(e, cp.data(), 2 * (u64)n_src, OCRGPU_HOST, &dc))) return r;
         k_exchange_apply_strided<<<nblk((u64)n_src * mx), 256, 0, e->stream>>>(e->d, n_src, stride_records, mx, dc, (const SendRec *)recs_dev, e->n_db);
+        remote_releases(e);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(e->stream));
         return 0;
@@ -3763,6 +3880,7 @@ extern "C" int ocrgpu_exchange_apply_strided(ocrgpu_engine_t *e, const void *rec
     const u32 *dc; if ((r = stage_in(e, pin, 2 * (u64)n_src, OCRGPU_HOST, &dc))) return r;
     HIPCHK(hipEventRecord(e->apply_ev[half], e->stream));
     k_exchange_apply_strided<<<nblk((u64)n_src * mx), 256, 0, e->stream>>>(e->d, n_src, stride_records, mx, dc, (const SendRec *)recs_dev, e->n_db);
+    remote_releases(e);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -3773,6 +3891,7 @@ extern "C" int ocrgpu_exchange_apply(ocrgpu_engine_t *e, const void *recs, u64 n
     int r = stage_reserve(e, rup(32 * n)); if (r) return r;
     const SendRec *dr; if ((r = stage_in(e, (const SendRec *)recs, n, where, &dr))) return r;
     k_exchange_apply<<<nblk(n), 256, 0, e->stream>>>(e->d, n, dr, e->n_db);
+    remote_releases(e);
     HIPCHK(hipGetLastError());
     if (where == OCRGPU_HOST) HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
@@ -3897,6 +4016,7 @@ static int xchg_land(ocrgpu_engine *e, const SendRec *recs, bool windows, u64 *o
     // the header sums, the state the last step ended in and the error counters ride on the same synchronisation (step_ahead does not poll)
     k_exchange_apply_hdr<<<d.n_loc * per, 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, recs, e->n_db, e->launch_index, e->pinned_dev, e->peer_cnt,
                                                              windows ? e->peer_win : nullptr, e->peer_round, e->peer_limit, ahead ? 1u : 0u, no_cascade, next_K0);
+    remote_releases(e); // (Lockable datablocks: never with rounds queued ahead -- the next run would have begun before these)
     HIPCHK(hipGetLastError());
     if (ahead) return 0; // rounds queued ahead: the caller synchronises once per batch
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -4188,7 +4308,10 @@ static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags
     do { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, nullptr, &fault, timed))) return r; } while (h[2] || h[3]); // what the main program sent settles first
     bool all_peer = g[0]->d.n_loc > 1;
     for (u32 i = 0; i < n; ++i) all_peer = all_peer && g[i]->peer_on;
-    const bool queue_ahead = all_peer && !timed && !timing && !getenv("OCRGPU_RX_POLLED") && !getenv("OCRGPU_RX_NO_AHEAD");
+    bool any_lockable = false;
+    for (u32 i = 0; i < n; ++i) any_lockable = any_lockable || g[i]->dbl != nullptr; // (their releases run behind the apply: the host drives every round)
+    if (any_lockable && (flags & OCRGPU_RX_NO_CASCADE)) FAIL(OCRGPU_EINVAL, "OCRGPU_RX_NO_CASCADE with Lockable datablocks: grants and releases are records that set off records");
+    const bool queue_ahead = all_peer && !any_lockable && !timed && !timing && !getenv("OCRGPU_RX_POLLED") && !getenv("OCRGPU_RX_NO_AHEAD");
     if (queue_ahead) { if ((r = resolve_run_ahead(g, n, flags, &levels, &fault))) return r; }
     else for (;;) {
         // launches queued for a level: the records that arrived, the level itself (that the run is then over is seen without a
@@ -4285,6 +4408,7 @@ extern "C" int ocrgpu_get_stats(ocrgpu_engine_t *e, ocrgpu_stats_t *out) { ENTER
 
 extern "C" int ocrgpu_snapshot(ocrgpu_engine_t *e) {
     ENTER(e);
+    if (e->dbl && e->d.n_loc > 1) FAIL(OCRGPU_ENOTSUP, "ocrgpu_snapshot: Lockable datablocks with partitions (the lines of remote requesters are not part of a snapshot)");
     int r = seal(e); if (r) return r;
     Dev &d = e->d; Snapshot &s = e->snap;
     if (s.valid) { HIPCHK(hipStreamSynchronize(e->stream)); snap_free(s); }

@@ -19,7 +19,7 @@ import torch  # noqa: F401
 import numpy as np
 
 from . import opstream as ops
-from .engine import F_WIDE_DB, SCRIPT_OP_DT, Engine
+from .engine import F_LOCKABLE_DB, F_WIDE_DB, SCRIPT_OP_DT, Engine
 from .opstream import OpStream, Result
 
 REC_BYTES = 32
@@ -81,7 +81,7 @@ class Partition:
         # streams with tile datablocks (OCRGPU_F_WIDE_DB): a record that carries a datablock takes 23 slots of its region (head + the
         # tile), and a TILE body that updated a copy sends one more home
         tiles = s.db_words == 64
-        per_rec = TILE_REC_SLOTS if tiles else 1
+        per_rec = TILE_REC_SLOTS if tiles else 2 if (flags & F_LOCKABLE_DB) else 1   # (Lockable: head + the datablock's home guid)
         if tiles:
             flags |= F_WIDE_DB
         cap = send_cap or max(4096, per_rec * (n_adddep + len(s.script) + (s.n_edt if tiles else 0)) + 1024)
