@@ -475,7 +475,7 @@ def main_partitioned(args, torch, dist, rank, world, local, backend):
     dist.destroy_process_group()
 
 
-PROFILE_TAG = "r03a_config2"
+PROFILE_TAG = "r03b_config2"
 
 
 def profiled_traffic(args, tag=PROFILE_TAG, kernel="k_step"):

@@ -87,7 +87,8 @@ typedef struct {
     u64 guid, outevt;
     u64 scope_latch;   /* latch of the finish scope this EDT was created in (0 = none): DECR in its epilogue */
     u64 own_latch;     /* EDT_PROP_FINISH: the latch of the scope it opens                                   */
-    u8 ran, destroyed;
+    u32 life;          /* 0 = created, 1 = its body has started, 2 = destroyed before it ran: one compare-and-swap decides between a
+                          worker that starts the body and a body elsewhere that calls ocrEdtDestroy */
     u64 creator;       /* serial of the body that created it (its check-in is issued when that body returns) */
 } Task;
 static Template *tpls; static size_t n_tpl, cap_tpl;
@@ -560,9 +561,8 @@ u8 ocrEdtDestroy(ocrGuid_t guid) {
     for (size_t i = n_task; i-- > 0;) {
         if (!task_chunk[i >> TASK_CHUNK_BITS]) continue;
         Task *t = task_at(i);
-        if (t->guid != (u64)guid.guid) continue; /* (an entry another body is still filling has guid 0 or a stale one: not ours) */
-        if (t->ran || t->destroyed) { UNLOCK(); return 0; }
-        t->destroyed = 1;
+        if (__atomic_load_n(&t->guid, __ATOMIC_ACQUIRE) != (u64)guid.guid) continue; /* (an entry another body is still filling has guid 0: the guid is published last) */
+        if (__sync_val_compare_and_swap(&t->life, 0u, 2u) != 0u) { UNLOCK(); return 0; } /* it has started, or was destroyed already */
         const u64 latch = t->scope_latch; const int mine = t->creator == cur_body;
         UNLOCK();
         if (latch) {
@@ -614,7 +614,8 @@ u8 ocrEdtCreate(ocrGuid_t *guid, ocrGuid_t tplGuid, u32 paramc, u64 *paramv, u32
         Op *l = emit(C_EVT_CREATE); l->a = t->own_latch; l->slot = OCREVT_LATCH; l->arg = 1;
     }
     const size_t ti = task_new();
-    *task_at(ti) = nt;
+    { Task *slot = task_at(ti); const u64 g = nt.guid; nt.guid = 0; *slot = nt; nt.guid = g;
+      __atomic_store_n(&slot->guid, g, __ATOMIC_RELEASE); } /* the guid last: ocrEdtDestroy's scan matches finished entries only */
     Op *o = emit(C_EDT_CREATE);
     o->a = t->guid; o->b = own_evt ? 0 : t->outevt; o->c = (u64)ti; o->slot = depc;
     if (finish) {
@@ -737,9 +738,8 @@ static TLS u64 my_bodies;         /* bodies this thread ran since it last added 
 static void run_index(u64 i) {
     if (rq_p0[i] >= n_task) die("engine returned an unknown task handle");
     const u64 ti = rq_p0[i];
-    Task t = *task_at(ti); /* a copy: the body's context outlives nothing, and ocrEdtDestroy may mark the entry meanwhile */
-    if (t.destroyed) return;
-    task_at(ti)->ran = 1;
+    if (__sync_val_compare_and_swap(&task_at(ti)->life, 0u, 1u) != 0u) return; /* destroyed before it could run (exactly one of the two wins) */
+    Task t = *task_at(ti); /* a copy: the body's context outlives nothing */
     if (rq_dc[i] != t.depc) die("depc mismatch for task %llu", (unsigned long long)ti);
     /* depv is the body's own: a body that blocks runs other bodies underneath it */
     ocrEdtDep_t small[16], *depv = t.depc <= 16 ? small : xrealloc(NULL, t.depc * sizeof *depv);

@@ -2,7 +2,7 @@
 # Round profile of the default bench workload (config 2): kernel trace + two PMC passes, each its own run.
 # usage (on the GPU box, from the repo root): bash tools/profile_config2.sh <tag>
 set -e -o pipefail
-tag=${1:-r03a}
+tag=${1:-r03b}
 root=$PWD
 out=$root/gpurun_out/$tag
 mkdir -p $out
