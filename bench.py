@@ -495,7 +495,7 @@ def profiled_traffic(args, tag=PROFILE_TAG, kernel="k_step"):
             if line.startswith("source:"):
                 src = line.strip().split("=")[-1]
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-                if kernel in line and ctr + " sum=" in line:
+                if (kernel + "(" in line or kernel + "<" in line) and ctr + " sum=" in line:   # ("k_async(", not "k_async_end(")
                     kb[ctr] = float(line.split("per dispatch ")[1].rstrip(")\n"))
         now = hashlib.sha256(open(os.path.join(here, "ocr_amd", "csrc", "ocrgpu.hip"), "rb").read()).hexdigest()[:16]
     except OSError:
