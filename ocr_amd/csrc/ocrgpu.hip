@@ -2144,6 +2144,9 @@ __global__ __launch_bounds__(ADD_DEP_BLK) void k_add_dep(Dev d, u64 n, const u64
     if (!reg) return;
     if ((u64)li + d.ctrl->chan_wait_used >= d.max_edges) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; } // waiters[] top end = CHANNEL rings
     d.log_src[li] = lx; d.log_rec[li] = lrec;
+    // the row length is counted HERE, on the line the classification has just read (registerWaiterEventHc's waitersCount++,
+    // hc-event.c:1096-1108), not by a pass over the whole log at every seal: that pass (clear + count) was half of the seal
+    atomicAdd(evt_deg(d, lx), 1u);
 }
 
 __global__ void k_satisfy(Dev d, u64 n, const u64 *evt, const u64 *db, const u32 *slot) {
@@ -2573,22 +2576,18 @@ __global__ void k_pop_ready(Dev d, u32 begin, u32 end, u32 max_edts, u32 max_dep
 }
 
 // ---- CSR (re)build from the registration log: count -> scan -> fill --------------------------------
-__global__ void k_csr_clear(Dev d, u32 n_evt_total) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_evt_total) *evt_deg(d, i) = 0;
-    if (i == 0) d.ctrl->max_row = 0;
-}
-__global__ void k_csr_count(Dev d) {
-    u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        u32 x = d.log_src[i];
-        if ((*evt_state(d, x) & 0xFF) == ST_LIVE) atomicAdd(evt_deg(d, x), 1u);
-    }
-}
+// (row lengths are kept current by k_add_dep; an event record starts at 0 when it is created, and snapshot / restore carry the
+// lengths with the records, in step with Ctrl.log_tail.  Only LIVE events' rows are filled and ever read.)
 __global__ void k_csr_gather_deg(Dev d, u32 n, u32 *deg) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     u32 m = 0;
-    if (i < n) { deg[i] = *evt_deg(d, i); if (i >= d.max_evt) m = deg[i]; } // (rows of EDT output events: the ones k_async fans out in numbers)
+    if (i < n) { // rows for LIVE events only (what k_csr_fill fills, and all that is ever read): an event that has fired keeps no room in waiters[]
+        u32 *dp = evt_deg(d, i);
+        u32 v = *dp;
+        if (v && (*evt_state(d, i) & 0xFF) != ST_LIVE) { v = 0; *dp = 0; }
+        deg[i] = v;
+        if (i >= d.max_evt) m = v; // (rows of EDT output events: the ones k_async fans out in numbers)
+    }
     for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_xor(m, o); m = x > m ? x : m; }
     if (lane_id() == 0 && m > AMAX_ROW) atomicMax(&d.ctrl->max_row, m); // (only rows that matter to the choice of path cost an atomic)
 }
@@ -3188,9 +3187,8 @@ static int seal(ocrgpu_engine *e) {
     // only indices in use matter: explicit [0,n_evt) and output events [max_evt, max_evt+n_edt)
     u32 used = d.max_evt + e->n_edt;
     (void)n_evt_total;
-    k_csr_clear<<<nblk(used), 256, 0, e->stream>>>(d, used);
     u32 g = nblk(e->edges_upper); if (g > 4096) g = 4096; if (g == 0) g = 1;
-    k_csr_count<<<g, 256, 0, e->stream>>>(d);
+    HIPCHK(hipMemsetAsync(&d.ctrl->max_row, 0, 4, e->stream));
     k_csr_gather_deg<<<nblk(used), 256, 0, e->stream>>>(d, used, e->tmp_a);
     int r = scan_u32(e, e->tmp_a, e->tmp_b, used, 0, nullptr);
     if (r) return r;
