@@ -2989,7 +2989,7 @@ static int scan_u32(ocrgpu_engine *e, const u32 *in, u32 *out, u64 n, u32 add0, 
 }
 
 static int scratch_setup(int device);
-extern "C" int ocrgpu_abi_version(void) { return 4; }
+extern "C" int ocrgpu_abi_version(void) { return 5; } // 5: tile and Lockable datablocks across partitions (records of several slots), a peer wait that gave up refuses further steps, no-alloc busy flag
 extern "C" const char *ocrgpu_last_error(void) { return g_err; }
 
 extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_config_t *cfg) {
