@@ -2146,7 +2146,12 @@ __global__ __launch_bounds__(ADD_DEP_BLK) void k_add_dep(Dev d, u64 n, const u64
     d.log_src[li] = lx; d.log_rec[li] = lrec;
     // the row length is counted HERE, on the line the classification has just read (registerWaiterEventHc's waitersCount++,
     // hc-event.c:1096-1108), not by a pass over the whole log at every seal: that pass (clear + count) was half of the seal
-    atomicAdd(evt_deg(d, lx), 1u);
+    // (the lanes of a wavefront that register on the FIRST lane's event count as one: a start event with 2M waiters registered in one
+    // batch was 2M atomics on one word, 24 ms; the other lanes -- other events -- go one by one)
+    const u32 x0 = __builtin_amdgcn_readfirstlane(lx);
+    const u64 same = __ballot(lx == x0);
+    if (lx != x0) atomicAdd(evt_deg(d, lx), 1u);
+    else if (lane_id() == (u32)(__ffsll((long long)same) - 1)) atomicAdd(evt_deg(d, x0), (u32)__popcll(same));
 }
 
 __global__ void k_satisfy(Dev d, u64 n, const u64 *evt, const u64 *db, const u32 *slot) {
@@ -2607,7 +2612,20 @@ __global__ void k_csr_fill(Dev d, u32 *cursor) {
     u32 n = d.ctrl->log_tail; if (n > d.max_edges) n = (u32)d.max_edges;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         u32 x = d.log_src[i];
-        if ((*evt_state(d, x) & 0xFF) == ST_LIVE) d.waiters[atomicAdd(&cursor[x], 1u)] = d.log_rec[i];
+        if ((*evt_state(d, x) & 0xFF) != ST_LIVE) continue;
+        // the lanes whose entry belongs to the first lane's event take their places with ONE atomic (the waiters of a start event or of
+        // a power-law hub sit side by side in the log: one atomic each on that event's cursor was tens of ms per seal)
+        const u32 x0 = __builtin_amdgcn_readfirstlane(x);
+        const u64 same = __ballot(x == x0);
+        u32 pos;
+        if (x != x0) pos = atomicAdd(&cursor[x], 1u);
+        else {
+            const int leader = __ffsll((long long)same) - 1;
+            u32 base = 0;
+            if ((int)lane_id() == leader) base = atomicAdd(&cursor[x0], (u32)__popcll(same));
+            pos = __shfl(base, leader) + rank_in(same);
+        }
+        d.waiters[pos] = d.log_rec[i];
     }
 }
 
@@ -2892,6 +2910,7 @@ struct ocrgpu_engine {
     ocrgpu_stats_t last; u64 launches_total, step_ns_total;
     u32 *pinned_done, *pinned_dev; u32 apply_flip; hipEvent_t apply_ev[2]; // the polled page and the device's address of it (k_report)
     DbLock *dbl; unsigned char *acq_mode; // OCRGPU_F_LOCKABLE_DB: the device tables (the device finds them through Ctrl)
+    bool irow_stale;                      // the rows were rebuilt since k_async's inline rows (ADev.irow) were last filled
     RWait *rwait; u64 *rrel;              // OCRGPU_F_LOCKABLE_DB with partitions (through Ctrl as well)
     u64 *tiles, *db_home;                 // OCRGPU_F_WIDE_DB: 64 words per explicit datablock, and the guid each was created under (through Ctrl as well)
     u32 pop_cursor, snap_pop_cursor; // ocrgpu_pop_ready: fired[] entries before this were handed out (or are built-ins)
@@ -3011,7 +3030,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
     e->csr_dirty = false; e->seal_epoch = 0; e->stage_dev = nullptr; e->stage_dev_cap = 0; e->stage_dev_off = 0; e->stage_host = nullptr; e->stage_host_cap = 0;
     e->scan_partials = nullptr; e->scan_partials_cap = 0; e->snap.valid = false; e->snap.dbl = nullptr; e->snap.tiles = nullptr; e->have_events = false;
-    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr; e->dbl = nullptr; e->acq_mode = nullptr; e->tiles = nullptr; e->db_home = nullptr; e->rwait = nullptr; e->rrel = nullptr;
+    e->apply_flip = 0; e->apply_ev[0] = e->apply_ev[1] = nullptr; e->dbl = nullptr; e->acq_mode = nullptr; e->tiles = nullptr; e->db_home = nullptr; e->rwait = nullptr; e->rrel = nullptr; e->irow_stale = true;
     e->launches_total = 0; e->step_ns_total = 0; e->launch_index = 8; e->pop_cursor = e->snap_pop_cursor = 0; e->defer_drain = false; e->send_cnt_dev = nullptr; e->step_grid = getenv("OCRGPU_STEP_GRID") ? (u32)atoi(getenv("OCRGPU_STEP_GRID")) : 2048u; memset(&e->last, 0, sizeof e->last);
     Dev &d = e->d; memset(&d, 0, sizeof d);
     { const char *mp = getenv("OCRGPU_SPREAD_WGS"); u32 v = mp ? (u32)atoi(mp) : 256u; d.spread_wgs = v < 1 ? 1u : (v > MAX_GRID ? (u32)MAX_GRID : v); }
@@ -3194,7 +3213,7 @@ static int seal(ocrgpu_engine *e) {
     if (r) return r;
     k_csr_set_rows<<<nblk(used), 256, 0, e->stream>>>(d, used, e->tmp_b, e->tmp_c);
     k_csr_fill<<<g, 256, 0, e->stream>>>(d, e->tmp_c);
-    if (e->async_mode && e->n_edt) k_irow_fill<<<nblk(e->n_edt), 256, 0, e->stream>>>(d, e->ad.irow, e->n_edt);
+    e->irow_stale = true; // (the inline rows k_async reads are filled when it next runs: a seal on the level-synchronous path does not pay for them)
     HIPCHK(hipGetLastError());
     e->csr_dirty = false; ++e->seal_epoch;
     return 0;
@@ -3626,6 +3645,7 @@ static int run_async(ocrgpu_engine *e) {
 #else
 #define HSTAMP()
 #endif
+    if (e->irow_stale && e->n_edt) { k_irow_fill<<<nblk(e->n_edt), 256, 0, e->stream>>>(d, a.irow, e->n_edt); e->irow_stale = false; }
     k_async_reset<<<1024, 256, 0, e->stream>>>(a); HSTAMP();
     k_async_init<<<1, 64, 0, e->stream>>>(d, a); HSTAMP();
     k_async_seed<<<256, 256, 0, e->stream>>>(d, a); HSTAMP();
