@@ -1397,7 +1397,11 @@ __global__ void k_end(Dev d, u32 K) { end_of_run(d, K); }
 #define A_SKIP 0xFFFFFFFFu   // queue entry id: padding of a hand-over's last block (the ticket is served, there is nothing to fire)
 #define A_BK 1024u          // ready entries a wave can keep for itself when the queues are full
 #define ALAT_BIAS 0x40000000u
-#define AMAX_ROW 1024u      // rows longer than this: level-synchronous path (its big-row pieces spread over the grid)
+#define AMAX_ROW 64u        // rows longer than this: level-synchronous path (its big-row pieces spread over the grid).  A wave takes a block of ~24 ready
+                            // EDTs and fans their rows out 64 edges at a time, each pass a round trip: 24 rows of 255 waiters (a level of trsm tasks
+                            // in the tiled Cholesky) are 96 dependent passes on ONE wave while a thousand others idle -- T = 256 took 13.5 ms this way
+                            // and 7.2 ms level by level.  OCRGPU_ASYNC_MAX_ROW overrides.
+#define AROW_TRACK 32u      // Ctrl.max_row is exact above this (below it nobody asks)
 #define AMAX_SEEDS 65536u   // more ready EDTs than this at the start: a wide DAG, atomic-rate bound, better served level by level
 struct alignas(128) AShard { u32 tail; u32 p0[31]; u32 head; u32 p1[31]; u64 acct; u32 p2[30]; }; // acct = entries consumed << 32 | busy waves
 struct ACtl { AShard sh[ANSH]; u32 old_tail[ANSH]; u32 L0, seed_begin, seed_end, max_level, n_lv_prev, total_out, pad[2]; };
@@ -2594,7 +2598,7 @@ __global__ void k_csr_gather_deg(Dev d, u32 n, u32 *deg) {
         if (i >= d.max_evt) m = v; // (rows of EDT output events: the ones k_async fans out in numbers)
     }
     for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_xor(m, o); m = x > m ? x : m; }
-    if (lane_id() == 0 && m > AMAX_ROW) atomicMax(&d.ctrl->max_row, m); // (only rows that matter to the choice of path cost an atomic)
+    if (lane_id() == 0 && m > AROW_TRACK) atomicMax(&d.ctrl->max_row, m); // (only rows that matter to the choice of path cost an atomic)
 }
 // the first AROW waiters of every EDT's output event, beside the lines and indexed by EDT (k_async: one trip for line and row)
 __global__ void k_irow_fill(Dev d, u64 *irow, u32 n_edt) {
@@ -2924,7 +2928,7 @@ struct ocrgpu_engine {
     // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
     ReclDev rc; u32 n_free_edt, n_free_evt, n_free_db, n_held; u64 mut_epoch; char *recl_tmp; size_t recl_tmp_cap;
     // the barrier-free resolve (k_async): its tables (null = this engine never takes that path), launch shape, runs so far
-    ADev ad; u32 async_waves; u64 async_runs; int async_mode; // async_mode: 0 never, 1 when the DAG allows and looks narrow (default), 2 whenever it allows
+    ADev ad; u32 async_waves; u64 async_runs; int async_mode; u32 async_max_row; // async_mode: 0 never, 1 when the DAG allows and looks narrow (default), 2 whenever it allows
 };
 
 static int dalloc(ocrgpu_engine *e, void **p, size_t bytes, bool zero = true) {
@@ -3102,6 +3106,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     TRY(dalloc(e, (void **)&e->rc.cnt, 4 * RC_N));
     memset(&e->ad, 0, sizeof e->ad); e->async_runs = 0; e->async_waves = 0;
     { const char *am = getenv("OCRGPU_ASYNC"); e->async_mode = am ? atoi(am) : 1; }
+    { const char *mr = getenv("OCRGPU_ASYNC_MAX_ROW"); e->async_max_row = mr ? (u32)strtoul(mr, nullptr, 10) : AMAX_ROW; if (e->async_max_row < AROW_TRACK) e->async_max_row = AROW_TRACK; }
     if ((cfg->flags & (OCRGPU_F_NANNY | OCRGPU_F_LOCKABLE_DB | OCRGPU_F_WIDE_DB | OCRGPU_F_NO_ASYNC)) || d.max_levels > (1u << 24)) e->async_mode = 0;
     if (e->async_mode) {
         const char *w = getenv("OCRGPU_ASYNC_WAVES"), *rf = getenv("OCRGPU_ASYNC_BLOCK");
@@ -3689,7 +3694,7 @@ extern "C" int ocrgpu_resolve(ocrgpu_engine_t *e, u64 max_levels, ocrgpu_stats_t
         }
         const u32 seeds = pn[33011] - pn[33010];
         const bool clean = pn[33040] == 0 && pn[33009] <= pn[33008] && pn[33043] <= pn[33042] && pn[33044] + 2u < e->d.max_levels;
-        if (clean && seeds && pn[33041] <= AMAX_ROW && (e->async_mode >= 2 || seeds <= AMAX_SEEDS)) { r = run_async(e); if (r) return r; done = true; }
+        if (clean && seeds && pn[33041] <= e->async_max_row && (e->async_mode >= 2 || seeds <= AMAX_SEEDS)) { r = run_async(e); if (r) return r; done = true; }
     }
     if (!done) { r = run_steps(e, 0xFFFFFFFFu, max_launches, true); if (r) return r; }
     if (stats_out) { r = fetch_stats(e, stats_out); if (r) return r; e->last = *stats_out; }

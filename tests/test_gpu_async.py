@@ -79,8 +79,9 @@ def test_both_paths_leave_the_same_record(name, golden_dir):
     m = (s.main["op"] == OP_ADD_DEP) & (ref_cls(s.main["a"]) == REF_OUTEVT)
     if m.any():
         max_row = int(np.bincount(ref_idx(s.main["a"][m]).astype(np.int64)).max())
-    # (a DAG whose EDTs have output events with more than 1024 waiters is left to the level-synchronous path, which splits such rows)
-    assert sa.async_runs == (1 if takes_barrier_free_path(s) and max_row <= 1024 and sa.fired else 0)
+    # (a DAG whose EDTs have output events with more than 64 waiters is left to the level-synchronous path, which spreads such rows
+    # over the grid: a block of long rows on one wave is a chain of dependent passes -- ocrgpu.hip AMAX_ROW)
+    assert sa.async_runs == (1 if takes_barrier_free_path(s) and max_row <= 64 and sa.fired else 0)
 
 
 def test_streams_outside_the_class_stay_level_synchronous():
@@ -140,6 +141,30 @@ def test_values_travel_between_waves():
     s = b.finish(second, start=start)
     r, st, _, _ = _run(s, 0)
     assert st.async_runs == 1 and r.diff(O.run_restatement(s)) == []
+
+
+@pytest.mark.parametrize("fan,limit,runs", [(64, None, 1), (65, None, 0), (300, "1024", 1), (1024, "4096", 1), (300, "16", 0)])
+def test_long_rows_choose_the_path(monkeypatch, fan, limit, runs):
+    """one EDT whose output event has `fan` waiters, and a second round behind them: barrier-free up to OCRGPU_ASYNC_MAX_ROW (default 64;
+    values below the 32 from which row lengths are tracked count as 32), level by level beyond -- the same record either way"""
+    from ocr_amd.opstream import EVT_ONCE, MODE_NULL, Builder
+    if limit is not None:
+        monkeypatch.setenv("OCRGPU_ASYNC_MAX_ROW", limit)
+    b = Builder(f"hub_{fan}")
+    start = b.evt(EVT_ONCE)
+    hub = b.edt(1)
+    b.add_dep(start, hub, 0, MODE_NULL)
+    mid = [b.edt(1) for _ in range(fan)]
+    for e in mid:
+        b.add_dep(b.out(hub), e, 0)
+    last = [b.edt(2) for _ in range(fan)]
+    for i, e in enumerate(last):
+        b.add_dep(b.out(mid[i]), e, 0)
+        b.add_dep(b.out(mid[(i * 7 + 3) % fan]), e, 1)
+    s = b.finish(last, start=start)
+    r, st, _, _ = _run(s, 0)
+    assert sum(st.err) == 0 and st.async_runs == runs
+    assert r.diff(O.run_restatement(s)) == []
 
 
 def test_device_digest_is_the_fold_of_the_record():
