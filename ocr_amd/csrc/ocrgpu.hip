@@ -1015,9 +1015,16 @@ __device__ void deferred_bodies(const Dev &d, u32 b_begin, u32 b_end, u32 h, u32
         }
         return;
     }
-    for (u32 base = b_begin + h * BLK; base < b_end; base += nh * BLK) { // workgroup-uniform trip count: tile bodies are wave-wide
-        const u32 i = base + threadIdx.x;
-        const u32 e = i < b_end ? d.fired[i] : INVALID;
+    // A wave runs eight tile bodies per pass and every pass is a round trip to the operands: with 64 entries per wave the owed range
+    // is eight dependent passes behind the two trips to the entry and its line, longer than the level it runs beside.  So the range is
+    // dealt as thinly as the helpers allow, down to 8 entries (one pass) per wave: the T = 256 Cholesky's levels average 3 700 tasks,
+    // which 2 048 workgroups take in one pass.
+    u32 per_wave = 64;
+    while (per_wave > 8u && (u64)nh * (per_wave / 2u) * (BLK / 64u) >= (u64)(b_end - b_begin)) per_wave >>= 1;
+    const u32 per_wg = per_wave * (BLK / 64u), wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+    for (u32 base = b_begin + h * per_wg; base < b_end; base += nh * per_wg) { // workgroup-uniform trip count: tile bodies are wave-wide
+        const u32 i = base + wv * per_wave + ln;
+        const u32 e = (ln < per_wave && i < b_end) ? d.fired[i] : INVALID;
         tile = false;
         if (e != INVALID) deferred_body<true>(d, e, tile, tt);
         tile_bodies_wave(d, tile, e, tt);
@@ -1107,6 +1114,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
         // (64 helpers looping over a 40 000-entry range take longer than the level beside them: 15.7 instead of 11.9 us);
         // the rest of the idle workgroups leave at once
         u32 n_help = (P.b_end - P.b_begin + BLK - 1) / BLK;
+        if (TILES) n_help = (P.b_end - P.b_begin + 8u * (BLK / 64u) - 1) / (8u * (BLK / 64u)); // (tile bodies: one pass of eight per wave where the helpers allow, deferred_bodies)
         if (n_help < HELPERS) n_help = HELPERS;
         if (n_help > gridDim.x - part) n_help = gridDim.x - part;
         if (blockIdx.x >= part && blockIdx.x < part + n_help) deferred_bodies<TILES>(d, P.b_begin, P.b_end, blockIdx.x - part, n_help);
