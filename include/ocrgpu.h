@@ -86,7 +86,7 @@ typedef struct {
 #define OCRGPU_F_NO_ASYNC 32u /* ocrgpu_resolve always runs level by level (one launch per level).  By default a resolve whose DAG is made of
                               * ONCE / LATCH events, NOP / HASH bodies without scripts and dependences whose payload is known at registration, and
                               * that starts from at most 65 536 ready EDTs, runs as ONE barrier-free kernel with the level carried as data (same
-                              * record).  Environment: OCRGPU_ASYNC=0 never, 2 whenever the DAG allows; OCRGPU_ASYNC_WAVES.        */
+                              * record).  Environment: OCRGPU_ASYNC=0 never, 2 whenever the DAG allows; OCRGPU_ASYNC_WAVES; OCRGPU_ASYNC_MAX_ROW. */
 #define OCRGPU_F_WIDE_DB 16u /* every ocrgpu_db_create datablock also carries an 8x8 tile of 64-bit integers (512 bytes, word w =
                               * ocrops_tile_init(value, w)) that OCRBODY_TILE bodies update in place -- the payload SURVEY.md s8d.3 names
                               * for the tiled Cholesky (regular-datablock.c:55-215: a datablock is its guid + a buffer the EDT writes).
