@@ -184,3 +184,21 @@ def test_device_digest_is_the_fold_of_the_record():
         want = want or host
         assert host == want
         p.eng.close()
+
+
+def test_sixty_resolves_leave_one_digest():
+    """the order in which the resident kernel fires EDTs differs from run to run; the record may not (tools/soak_async.py at test size)"""
+    s = ALL["layered_100k"]
+    p = engine.StreamProgram(s.with_main(s.main[:-1])).build()
+    p.eng.snapshot()
+    want = O.run_restatement(s)
+    ids = np.arange(s.n_edt, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        digest = int(engine.digest_term(ids, want.level[:s.n_edt], want.val[:s.n_edt]).sum(dtype=np.uint64))
+    for k in range(60):
+        p.eng.restore()
+        p.eng.event_satisfy_slot(p._guids(s.main[-1:]["a"]))
+        st = p.resolve()
+        assert st.async_runs == k + 1 and sum(st.err) == 0
+        assert p.eng.digest_edts(0, s.n_edt) == digest, k
+    p.eng.close()
