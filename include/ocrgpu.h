@@ -133,6 +133,12 @@ typedef struct {
 int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_config_t *cfg);
 int ocrgpu_fini(ocrgpu_engine_t *e);
 int ocrgpu_set_stream(ocrgpu_engine_t *e, void *hip_stream);    /* default: the NULL stream */
+/* A stream of the engine's own (hipStreamNonBlocking, destroyed with the engine) in place of the NULL stream: for several engines in one
+ * process -- partitions that share a GPU, one host thread that drives several GPUs -- whose kernels would otherwise all stand in one
+ * line.  The reference's counterpart is one comm / compute worker thread per policy domain (hc-comm-worker.c, hc-worker.c:52-265):
+ * policy domains do not wait for each other except through messages.  Device arrays passed with OCRGPU_DEVICE afterwards must be
+ * complete when the call is made. */
+int ocrgpu_stream_create(ocrgpu_engine_t *e);
 const char *ocrgpu_last_error(void);
 int ocrgpu_abi_version(void);
 

@@ -2908,7 +2908,7 @@ static void snap_free(Snapshot &s) {
 #define PIN_ERR 33020u // u32 index into pinned_done of the 8 error counters the last poll brought back
 struct ocrgpu_engine {
     u64 err_seen;  // sum of Ctrl.err[] the caller has been told about (OCRGPU_EFAULT)
-    int device; hipStream_t stream; ocrgpu_config_t cfg; Dev d;
+    int device; hipStream_t stream; hipStream_t own_stream /* ocrgpu_stream_create: destroyed with the engine */; ocrgpu_config_t cfg; Dev d;
     std::vector<void *> allocs;
     // host mirrors
     u32 n_edt, n_evt, n_db; u64 n_slots, n_script, script_cap, lazy_cap; u64 counter; u64 edges_upper;
@@ -3020,7 +3020,7 @@ static int scan_u32(ocrgpu_engine *e, const u32 *in, u32 *out, u64 n, u32 add0, 
 }
 
 static int scratch_setup(int device);
-extern "C" int ocrgpu_abi_version(void) { return 5; } // 5: tile and Lockable datablocks across partitions (records of several slots), a peer wait that gave up refuses further steps, no-alloc busy flag
+extern "C" int ocrgpu_abi_version(void) { return 6; } // 6: ocrgpu_stream_create; 5: tile and Lockable datablocks across partitions (records of several slots), a peer wait that gave up refuses further steps, no-alloc busy flag
 extern "C" const char *ocrgpu_last_error(void) { return g_err; }
 
 extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_config_t *cfg) {
@@ -3034,7 +3034,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     HIPCHK(hipSetDevice(device));
     { int sr = scratch_setup(device); if (sr) return sr; } // this GPU's address of the static scratch array (ocrgpu_pop_ready_noalloc)
     ocrgpu_engine *e = new ocrgpu_engine();
-    e->device = device; e->stream = 0; e->cfg = *cfg; e->err_seen = 0;
+    e->device = device; e->stream = 0; e->own_stream = nullptr; e->cfg = *cfg; e->err_seen = 0;
     e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0;
     e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_fence_wave = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false; e->poisoned = false; e->ra_ev[0] = e->ra_ev[1] = nullptr;
     e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
@@ -3196,11 +3196,24 @@ extern "C" int ocrgpu_fini(ocrgpu_engine_t *e) {
     for (int i = 0; i < 2; ++i) if (e->apply_ev[i]) (void)hipEventDestroy(e->apply_ev[i]);
     for (int i = 0; i < 2; ++i) if (e->ra_ev[i]) (void)hipEventDestroy(e->ra_ev[i]);
     if (e->have_events) { (void)hipEventDestroy(e->ev0); (void)hipEventDestroy(e->ev1); }
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
     return 0;
 }
 
 extern "C" int ocrgpu_set_stream(ocrgpu_engine_t *e, void *s) { if (!e) FAIL(OCRGPU_EINVAL, "null engine"); e->stream = (hipStream_t)s; return 0; }
+// Several engines in ONE process (partitions that share a GPU, or one host thread driving several GPUs) all launch on the NULL stream
+// by default: one queue, every kernel of every partition in line behind the others.  This gives the engine a stream of its own
+// (hipStreamNonBlocking; it belongs to the engine and goes with it).  What was queued on the old stream is waited for first.  From
+// then on device arrays handed in with OCRGPU_DEVICE must be complete before the call (no implicit order with the NULL stream).
+extern "C" int ocrgpu_stream_create(ocrgpu_engine_t *e) {
+    if (!e) FAIL(OCRGPU_EINVAL, "null engine");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!e->own_stream) HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
+    return 0;
+}
 extern "C" int ocrgpu_sync(ocrgpu_engine_t *e) { if (!e) FAIL(OCRGPU_EINVAL, "null engine"); HIPCHK(hipStreamSynchronize(e->stream)); return 0; }
 extern "C" int ocrgpu_set_hash_tag_base(ocrgpu_engine_t *e, u64 b) { if (!e) FAIL(OCRGPU_EINVAL, "null engine"); e->d.hash_tag_base = b; return 0; }
 

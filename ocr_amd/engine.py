@@ -67,7 +67,7 @@ SCRIPT_OP_DT = np.dtype([("target", "<u8"), ("payload", "<u8"), ("slot", "<u4"),
                          ("pad", "<u2")])
 assert SCRIPT_OP_DT.itemsize == 24
 
-EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_last_error", "ocrgpu_abi_version",
+EXPORTS = ["ocrgpu_init", "ocrgpu_fini", "ocrgpu_set_stream", "ocrgpu_stream_create", "ocrgpu_last_error", "ocrgpu_abi_version",
            "ocrgpu_guid_reserve", "ocrgpu_guid_put", "ocrgpu_guid_tryput", "ocrgpu_guid_get", "ocrgpu_guid_remove",
            "ocrgpu_event_create", "ocrgpu_db_create", "ocrgpu_edt_create", "ocrgpu_edt_set_scripts",
            "ocrgpu_set_hash_tag_base", "ocrgpu_add_dependence", "ocrgpu_event_satisfy_slot", "ocrgpu_event_destroy", "ocrgpu_edt_release_dbs",
@@ -399,6 +399,10 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.ocrgpu_sync(self.h))
+
+    def stream_create(self):
+        """a stream of the engine's own in place of the NULL stream (several engines in one process: ocrgpu.h)"""
+        self._chk(self.lib.ocrgpu_stream_create(self.h))
 
     def stats(self):
         st = Stats()

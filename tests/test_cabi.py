@@ -18,7 +18,7 @@ def test_header_and_library_agree():
     lib = engine.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ocrgpu_abi_version() == 5
+    assert lib.ocrgpu_abi_version() == 6
 
 
 def test_no_cpu_fallback():
