@@ -4055,7 +4055,13 @@ static int xchg_post(ocrgpu_engine *e, bool hdr_fresh) {
 }
 static int xchg_land(ocrgpu_engine *e, const SendRec *recs, bool windows, u64 *out4, bool ahead = false, u32 no_cascade = 0, u32 next_K0 = 0) {
     Dev &d = e->d;
-    u32 per = (d.send_cap + 254u) / 256u; if (per > 32u) per = 32u; // workgroups per source region
+    // workgroups per source region: 32 for two partitions, 32 / n_loc (at least 4) beyond -- every workgroup ends in a device-scope
+    // release and a ticket on one word, and while it waits for its source's arrival it holds its wave slots (partitions that share a
+    // GPU: 8 x 32 x 8 workgroups of waiting applies filled the chip).  Measured with a stream per partition, 4 partitions 118 -> 108 us
+    // per level, 8 partitions 207 -> 161.  OCRGPU_APPLY_BLOCKS overrides.
+    u32 per = (d.send_cap + 254u) / 256u, lim = d.n_loc <= 2 ? 32u : (32u / d.n_loc < 4u ? 4u : 32u / d.n_loc);
+    { static const char *ab = getenv("OCRGPU_APPLY_BLOCKS"); if (ab && atoi(ab) > 0) lim = (u32)atoi(ab) > 32u ? 32u : (u32)atoi(ab); }
+    if (per > lim) per = lim;
     int r = xchg_words(e); if (r) return r;
     // the header sums, the state the last step ended in and the error counters ride on the same synchronisation (step_ahead does not poll)
     k_exchange_apply_hdr<<<d.n_loc * per, 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, recs, e->n_db, e->launch_index, e->pinned_dev, e->peer_cnt,
