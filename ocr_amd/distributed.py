@@ -367,7 +367,7 @@ def connect_peer_windows(parts):
         p.eng.peer_connect(handles)
     # From here on the partitions only meet through their windows (arrival words, as between devices), so each gets a stream of its
     # own: on the NULL stream they all share, every kernel of every partition stands in one line (2 partitions on one GPU: 103 us
-    # per level that way, 58 with a stream each; 8 partitions: 342 -> 125).  OCRGPU_RIG_SHARED_STREAM=1 keeps the old arrangement.
+    # per level that way, 58 with a stream each; 8 partitions: 342 -> 161).  OCRGPU_RIG_SHARED_STREAM=1 keeps the old arrangement.
     if len(parts) > 1 and not os.environ.get("OCRGPU_RIG_SHARED_STREAM"):
         for p in parts:
             p.eng.sync()
