@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) pw[k] = (u32)k < depc ? (sl[k] & 0x7FFFFFFFu) : 0u;
                 }
-                if (!defer && !(TILES && OCRBODY_KIND(body) == OCRBODY_TILE)) {
+                if (TILES != 2 && !defer && !(TILES && OCRBODY_KIND(body) == OCRBODY_TILE)) { // (TILES == 2: the bodies of this level ran in k_bodies_pre)
 #pragma unroll
                     for (int k = 0; k < 8; ++k) gb[k] = db_gather(d, pw[k]);
                 }
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                 // With other partitions around, a satisfy may carry this EDT's output DB away by value in this very
                 // launch, so the body runs first; on a single partition it runs after the fan-out (off the critical path).
                 const bool host_body = kind == OCRBODY_HOST; // taskExecute happens on the host (ocrgpu_pop_ready)
-                if (body_first && !host_body && kind != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, body); // (tile datablocks: one partition only)
+                if (TILES != 2 && body_first && !host_body && kind != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, body); // (tile engines with partitions: k_bodies_pre)
                 if (body & BODY_F_SCRIPT) { // the body's own ocrEventSatisfySlot / ocrEventDestroy calls
                     u32 sb = d.edt_script_begin[e], sn = d.edt_script_len[e];
                     for (u32 k = 0; k < sn; ++k) {
@@ -1220,20 +1220,6 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
                 }
             }
             n_fired += __popcll(__ballot(mine)); n_evt_sat += __popcll(__ballot(epi));
-            if (TILES == 2 && body_first) {
-                // With other partitions around the fan-out below carries this level's tiles away BY VALUE, so the TILE bodies run first
-                // (they are wave-wide: here, outside the per-lane block above); the barrier makes what they stored visible to the other
-                // waves of the workgroup, whose lanes write the records (edge-balanced fan-out: not the EDT's own lane).  A body that
-                // updated a COPY of another partition's datablock sends the contents home (hc-dist writes a released RW / EW proxy back).
-                const bool tb = mine && OCRBODY_KIND(body) == OCRBODY_TILE;
-                tile_bodies_wave(d, tb, e, tt);
-                __syncthreads();
-                const u32 tg = tb ? tile_target(tt) : 0u;
-                if (tg && tg - 1 < d.max_db) {
-                    const u64 home = c->db_home[tg - 1];
-                    if (OCRGPU_GUID_LOCATION(home) != d.location) emit_remote_tile(d, home, 0u, XF_TILE_WB, d.db[tg - 1], tg - 1);
-                }
-            }
             STAMP(1);
             u32 total;
             u32 incl = block_inclusive_scan(deg, wave_sums, total);
@@ -1243,8 +1229,8 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
             STAMP(2);
             if (total) fan_out<NANNY, LOCKABLE, TILES>(d, S, seg, BLK, total, &lds_base, n_edt_sat, n_evt_sat);
             STAMP(3);
-            if (mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST && OCRBODY_KIND(body) != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, body);
-            if (TILES && !(TILES == 2 && body_first)) tile_bodies_wave(d, mine && !defer && OCRBODY_KIND(body) == OCRBODY_TILE, e, tt);
+            if (TILES != 2 && mine && !body_first && !defer && OCRBODY_KIND(body) != OCRBODY_HOST && OCRBODY_KIND(body) != OCRBODY_TILE) run_body(d, e, id, depc, sl, gb, body);
+            if (TILES == 1) tile_bodies_wave(d, mine && !defer && OCRBODY_KIND(body) == OCRBODY_TILE, e, tt);
         }
     } else {
         // ---- queued satisfies: API calls, fired chained events, big-row pieces, direct EDT pre-slot satisfies ----
@@ -1302,6 +1288,40 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
 #ifdef OCRGPU_STAMPS
     if (threadIdx.x == 0 && K - (u32)d.dbg[15] < STAMP_LAUNCHES) STAMP_AT(1) = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// Tile engines WITH partitions: the fan-out of a level carries its tiles away BY VALUE (records), so the bodies of a level run before
+// it -- in a launch of their own in front of the FIRE launch.  (Inline in k_step, in front of the fan-out, the tile code took the
+// kernel to 249 VGPRs and 312 bytes of scratch: 61 us per launch, 22 for one that finds nothing to do; T = 256 on 8 partitions of
+// one GPU 1.3 s per resolve.)  The launch decides what launch K will do exactly as k_step(K) does -- from launch K - 1's state and
+// append counters, which nothing writes in between -- and, when that is a level, runs its bodies dealt 8 entries per wave (one pass
+// of tile_bodies_wave) where the grid allows.  A body that updated a COPY of another partition's datablock sends the contents home
+// (hc-dist writes a released RW / EW proxy back, hc-dist-policy.c:382-700).
+__global__ __launch_bounds__(BLK) void k_bodies_pre(Dev d, u32 K) {
+    const Ctrl *c = d.ctrl;
+    const State P = c->state[(K - 1) & 1];
+    if (P.done) return;
+    const u32 r_total = P.r_total + c->cnt_r[(K - 1) % 3].v;
+    u32 q_total = P.q_total + c->cnt_q[(K - 1) % 3].v;
+    if (q_total > d.q_cap) q_total = d.q_cap;
+    if (q_total > P.q_end || !P.allow_fire || !(r_total > P.r_end)) return; // launch K applies queued records, or has no level to fire
+    const u32 b_begin = P.r_end, b_end = r_total, nh = gridDim.x, h = blockIdx.x;
+    u32 per_wave = 64;
+    while (per_wave > 8u && (u64)nh * (per_wave / 2u) * (BLK / 64u) >= (u64)(b_end - b_begin)) per_wave >>= 1;
+    const u32 per_wg = per_wave * (BLK / 64u), wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+    for (u32 base = b_begin + h * per_wg; base < b_end; base += nh * per_wg) { // workgroup-uniform trip count
+        const u32 i = base + wv * per_wave + ln;
+        const u32 e = (ln < per_wave && i < b_end) ? d.fired[i] : INVALID;
+        bool tile = false; u32 tt[3] = {0, 0, 0};
+        if (e != INVALID) deferred_body<true>(d, e, tile, tt);
+        tile_bodies_wave(d, tile, e, tt);
+        __syncthreads(); // the rows of a tile were stored by the eight lanes of its group: all there before the record below reads them
+        const u32 tg = tile ? tile_target(tt) : 0u;
+        if (tg && tg - 1 < d.max_db) {
+            const u64 home = c->db_home[tg - 1];
+            if (OCRGPU_GUID_LOCATION(home) != d.location) emit_remote_tile(d, home, 0u, XF_TILE_WB, d.db[tg - 1], tg - 1);
+        }
+    }
 }
 
 // A run that stopped on its launch budget pays the bodies it owes before the caller can look at values.
@@ -3253,6 +3273,7 @@ static int seal(ocrgpu_engine *e) {
 static void launch_step(ocrgpu_engine *e, u32 grid, u32 K) {
     const bool nanny = (e->cfg.flags & OCRGPU_F_NANNY) != 0;
     const Dev &d = e->d;
+    if (e->tiles && d.n_loc > 1) k_bodies_pre<<<grid, BLK, 0, e->stream>>>(d, K); // (the bodies of the level launch K fires, if it fires one)
     if (e->tiles && d.n_loc > 1) { if (nanny) k_step<true, 0, 2><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, 0, 2><<<grid, BLK, 0, e->stream>>>(d, K); } // tile datablocks that cross partitions
     else if (e->tiles) { if (nanny) k_step<true, 0, 1><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, 0, 1><<<grid, BLK, 0, e->stream>>>(d, K); }
     else if (e->dbl && d.n_loc > 1) { if (nanny) k_step<true, 2, 0><<<grid, BLK, 0, e->stream>>>(d, K); else k_step<false, 2, 0><<<grid, BLK, 0, e->stream>>>(d, K); } // datablocks arbitrated by their owners

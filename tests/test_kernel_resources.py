@@ -34,13 +34,16 @@ def test_k_step_instantiations_keep_their_registers(tmp_path):
     assert len(steps) == 10, sorted(usage)[:10]
     for k, v in steps.items():
         tiles = "ELi1EE" in k                 # OCRGPU_F_WIDE_DB on one partition: the 8x8 tile bodies are compiled in
-        xtiles = "ELi2EE" in k                # ... with other partitions: tiles leave by value (23 record slots each)
         xlock = "ELi2ELi0EE" in k             # OCRGPU_F_LOCKABLE_DB with other partitions: datablocks arbitrated by their owners
-        if xtiles or xlock:                   # paths of their own, held to nothing but to compiling
+        if xlock:                             # a path of its own, held to nothing but to compiling
             continue
+        # ("ELi2EE": tile datablocks with other partitions -- its bodies run in k_bodies_pre, so it is held to the default kernel's
+        # numbers; with the tile code inline in front of the fan-out it had 249 VGPRs and 312 bytes of scratch, 61 us per launch)
         assert v["ScratchSize"] == 0 and v["VGPRs Spill"] == 0, (k, v)
         if tiles:
             assert v["VGPRs"] <= 168 and v["Occupancy"] >= 3, (k, v)
         else:
             assert v["VGPRs"] <= 128 and v["Occupancy"] >= 4, (k, v)
+    pre = usage["_Z12k_bodies_pre3Devj"]
+    assert pre["ScratchSize"] == 0 and pre["VGPRs"] <= 128, pre
     print({k: (v["VGPRs"], v["ScratchSize"], v["Occupancy"]) for k, v in steps.items()})
