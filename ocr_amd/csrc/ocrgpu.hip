@@ -762,7 +762,7 @@ __device__ void emit_remote_tile(const Dev &d, u64 guid, u32 slot, u32 xflags, u
     const u64 *t = d.ctrl->tiles + OCROPS_TILE_WORDS * (size_t)dbi;
     const u64 home = d.ctrl->db_home[dbi];
     auto word = [&](u32 w) -> u64 { return w < OCROPS_TILE_WORDS ? t[w] : w == OCROPS_TILE_WORDS ? home : 0ull; };
-#pragma unroll 2
+#pragma unroll 11
     for (u32 k = 0; k + 1 < TILE_REC_SLOTS; ++k) r[1 + k] = SendRec{word(3 * k), k, XF_CONT, word(3 * k + 1), word(3 * k + 2)};
 }
 // XT: the caller may meet tile datablocks that cross partitions (compiled out of the k_step instantiations that cannot: the code costs
@@ -2296,7 +2296,8 @@ __device__ __forceinline__ u32 wave_reserve_one(u32 *counter) {
 __device__ __forceinline__ u64 tile_from_record(const Dev &d, const SendRec *head, u32 idx) {
     u64 *t = d.ctrl->tiles + OCROPS_TILE_WORDS * (size_t)idx;
     u64 home = 0;
-#pragma unroll 2
+#pragma unroll 11 // (one lane copies the 22 continuation slots of its record: eleven 32-byte loads in flight at a time, not two -- the apply of a
+                  // level of tile records was a chain of eleven round trips per record)
     for (u32 k = 0; k + 1 < TILE_REC_SLOTS; ++k) {
         const SendRec c = head[1 + k];
         const u64 w[3] = {c.guid, c.value, c.tag};
@@ -4081,7 +4082,7 @@ static int xchg_land(ocrgpu_engine *e, const SendRec *recs, bool windows, u64 *o
     // GPU: 8 x 32 x 8 workgroups of waiting applies filled the chip).  Measured with a stream per partition, 4 partitions 118 -> 108 us
     // per level, 8 partitions 207 -> 161.  OCRGPU_APPLY_BLOCKS overrides.
     u32 per = (d.send_cap + 254u) / 256u, lim = d.n_loc <= 2 ? 32u : (32u / d.n_loc < 4u ? 4u : 32u / d.n_loc);
-    { static const char *ab = getenv("OCRGPU_APPLY_BLOCKS"); if (ab && atoi(ab) > 0) lim = (u32)atoi(ab) > 32u ? 32u : (u32)atoi(ab); }
+    { static const char *ab = getenv("OCRGPU_APPLY_BLOCKS"); if (ab && atoi(ab) > 0) lim = (u32)atoi(ab) > 512u ? 512u : (u32)atoi(ab); }
     if (per > lim) per = lim;
     int r = xchg_words(e); if (r) return r;
     // the header sums, the state the last step ended in and the error counters ride on the same synchronisation (step_ahead does not poll)
