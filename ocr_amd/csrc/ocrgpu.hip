@@ -536,7 +536,8 @@ __device__ __forceinline__ u32 *waiter_link(const Dev &d, u32 w) {
 // ascending guid).  A datablock made by ocrgpu_db_create -- or a copy of one that came in a record -- goes by the guid it was created
 // under, which is the same on every partition; the output datablock of an EDT is only ever contended where it lives and goes by its
 // index there, behind all the others.
-__device__ __forceinline__ u64 acq_key(const Dev &d, u32 p /* index + 1 */) {
+template <bool XL> __device__ __forceinline__ u64 acq_key(const Dev &d, u32 p /* index + 1 */) {
+    if (!XL) return p - 1u < d.max_db ? (u64)p : (0x8000000000000000ull | p); // one partition: creation order IS ascending guid order (no trip to db_home[])
     if (p - 1u < d.max_db) { const u64 g = d.ctrl->db_home ? d.ctrl->db_home[p - 1u] : 0ull; return g ? (g & 0x7FFFFFFFFFFFFFFFull) : (u64)p; }
     return 0x8000000000000000ull | p;
 }
@@ -575,10 +576,10 @@ __device__ __forceinline__ bool acq_walk(const Dev &d, u32 e) {
     const u32 *sl = depc <= INLINE_SLOTS ? L->slot : d.slots + L->slot[0];
     const unsigned char *md = d.ctrl->acq_mode + acq_index(d, e, depc, L->slot[0], 0u);
     const u32 lk = (u32)L->val;
-    u64 last = lk ? acq_key(d, sl[lk - 1u] & 0x7FFFFFFFu) : 0ull;
+    u64 last = lk ? acq_key<XL>(d, sl[lk - 1u] & 0x7FFFFFFFu) : 0ull;
     for (;;) {
         u64 best = ~0ull; u32 bk = 0; // the next datablock in ascending order; named twice = the mode of its lowest pre-slot (stable sort :459-477)
-        for (u32 k = 0; k < depc; ++k) { const u32 p = sl[k] & 0x7FFFFFFFu; if (!p) continue; const u64 key = acq_key(d, p); if (key > last && key < best) { best = key; bk = k; } }
+        for (u32 k = 0; k < depc; ++k) { const u32 p = sl[k] & 0x7FFFFFFFu; if (!p) continue; const u64 key = acq_key<XL>(d, p); if (key > last && key < best) { best = key; bk = k; } }
         if (best == ~0ull) { L->val = 0; return true; }
         last = best;
         reinterpret_cast<u32 *>(&L->val)[0] = bk + 1u; // moved on before the attempt, like frontierSlot (:491)
@@ -622,9 +623,9 @@ __device__ __forceinline__ void release_all(const Dev &d, const u32 *sl, u32 dep
     for (u32 k = 0; k < depc; ++k) {
         const u32 p = sl[k] & 0x7FFFFFFFu;
         if (!p) continue;
-        const u64 key = acq_key(d, p);
+        const u64 key = acq_key<XL>(d, p);
         bool dup = false;
-        for (u32 j = 0; j < k; ++j) { const u32 q = sl[j] & 0x7FFFFFFFu; dup |= q != 0u && acq_key(d, q) == key; }
+        for (u32 j = 0; j < k; ++j) { const u32 q = sl[j] & 0x7FFFFFFFu; dup |= q != 0u && acq_key<XL>(d, q) == key; }
         if (dup) continue;
         const u64 home = XL ? acq_remote_home(d, p) : 0ull;
         if (XL && home) emit_remote_raw(d, home, 0u, XF_REL, 0ull, 0ull); // its owner takes this holder off (lockableRelease runs there)
