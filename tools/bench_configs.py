@@ -165,5 +165,7 @@ def run(spec, steps=3, warmup=1, parity=True):
 
 if __name__ == "__main__":
     specs = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if any(sp.startswith("powerlaw:") for sp in specs):   # the generator sorts on the GPU through torch, which ships its own HIP runtime:
+        import torch  # noqa: F401                          # it has to be loaded before libocrgpu.so pulls in /opt/rocm's (ocr_amd/distributed.py)
     for sp in specs:
         run(sp, parity="--no-parity" not in sys.argv)
