@@ -149,7 +149,7 @@ struct alignas(128) State {
 struct alignas(128) Cnt { u32 v; u32 pad[31]; };
 struct alignas(128) Ctrl {
     // between runs ("absolute" view, used by the API kernels and by k_begin / k_end)
-    u32 level, r_end, q_begin, async_block /* objects / dependences k_async does not take (see there) */, n_levels, b_begin, b_end, max_row /* longest waiter row (seal) */, pad1[24];
+    u32 level, r_end, q_begin, async_block /* objects / dependences k_async does not take (see there) */, n_levels, b_begin, b_end, max_row /* longest waiter row (seal) */, noop_steps /* k_step launches that found nothing to do (rounds queued ahead size their launch budget by it) */, pad1[23];
     u32 r_tail; u32 pad2[31];   // atomics (own cache lines)
     u32 q_tail; u32 pad3[31];
     u32 log_tail; u32 rdst_tail; u32 chan_count, chan_wait_used, chan_sat_used;
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     Ctrl *c = d.ctrl;
     // ---- replicated phase decision (the scheduler's "get work", on the device, without a hand-over) ----
     const State P = c->state[(K - 1) & 1];
-    if (P.done) { if (blockIdx.x == 0 && threadIdx.x == 0) c->state[K & 1] = P; return; }
+    if (P.done) { if (blockIdx.x == 0 && threadIdx.x == 0) { c->state[K & 1] = P; atomicAdd(&c->noop_steps, 1u); } return; }
     const u32 r_total = P.r_total + c->cnt_r[(K - 1) % 3].v;
     u32 q_total = P.q_total + c->cnt_q[(K - 1) % 3].v;
     if (q_total > d.q_cap) q_total = d.q_cap;
@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
         if (n_help > gridDim.x - part) n_help = gridDim.x - part;
         if (blockIdx.x >= part && blockIdx.x < part + n_help) deferred_bodies<TILES>(d, P.b_begin, P.b_end, blockIdx.x - part, n_help);
     }
-    if (N.done) return;
+    if (N.done) { if (blockIdx.x == 0 && threadIdx.x == 0 && !owed) atomicAdd(&c->noop_steps, 1u); return; } // (a launch that only notices the end)
     Step S;
     S.mode = N.mode; S.r_begin = N.r_begin; S.r_end = N.r_end; S.q_begin = N.q_begin; S.q_end = N.q_end;
     S.r_base = r_total; S.q_base = q_total; S.cnt_r = &c->cnt_r[K % 3].v; S.cnt_q = &c->cnt_q[K % 3].v;
@@ -1358,20 +1358,8 @@ __global__ void k_begin(Dev d, u32 K0, u32 allow_fire, u32 force_level) { begin_
 #define RA_ROUND 1032u  // rounds applied since k_ra_init
 #define RA_STOP_AT 1033u // 1 + the round in which RA_STOP was set (what the host goes by: see resolve_run_ahead)
 #define RA_BEHIND 1034u  // a NO_CASCADE run was stopped because a partition had fallen a level behind
-__global__ void k_ra_init(u32 *w) { w[RA_STOP] = 0; w[RA_HOLD] = 0; w[RA_LEVELS] = 0; w[RA_KIND] = 0; w[RA_ACT] = 0; w[RA_ACT + 1] = 0; w[RA_ROUND] = 0; w[RA_STOP_AT] = 0; w[RA_BEHIND] = 0; }
-__device__ __forceinline__ void begin_auto(const Dev &d, u32 K0, u32 *w) {
-    u32 fire = 0, force = 0;
-    if (w[RA_STOP]) w[RA_KIND] = 2;
-    else if (w[RA_HOLD]) {
-        const State *P = &d.ctrl->state[(K0 - 1) & 1]; // how the last run ended: one that ran out of launches goes on with what it had left
-        if (!P->done) { fire = P->allow_fire; force = fire ? OCRGPU_STEP_FORCE_LEVEL : 0u; }
-        w[RA_KIND] = 0;
-    } else { fire = 1; force = OCRGPU_STEP_FORCE_LEVEL; w[RA_KIND] = 1; w[RA_ACT] = 0; w[RA_ACT + 1] = 0; }
-    begin_run(d, K0, fire, force);
-}
-__global__ void k_begin_auto(Dev d, u32 K0, u32 *w) { begin_auto(d, K0, w); }
-// End of a run whose last launch was K: fold the run state back into the between-runs view; if the record
-// log is fully consumed, rewind it (keeps q_cap small).
+#define RA_SHORT 1035u   // rounds whose step ran out of launches (it went on in the next round)
+__global__ void k_ra_init(u32 *w) { w[RA_STOP] = 0; w[RA_HOLD] = 0; w[RA_LEVELS] = 0; w[RA_KIND] = 0; w[RA_ACT] = 0; w[RA_ACT + 1] = 0; w[RA_ROUND] = 0; w[RA_STOP_AT] = 0; w[RA_BEHIND] = 0; w[RA_SHORT] = 0; }
 // What launch K + 1 would find, without launching it: the log totals with launch K's appends, and whether it would only notice that
 // the run is over (k_step's phase decision: nothing queued, no fire budget left, no bodies owed).  The level loops across
 // partitions go by this instead of paying a launch per level for the notice.
@@ -1386,6 +1374,19 @@ __device__ __forceinline__ RunView run_view(const Dev &d, u32 K) {
     v.over = !(v.q_total > N->q_end) && !N->allow_fire && !(N->b_end > N->b_begin);
     return v;
 }
+__device__ __forceinline__ void begin_auto(const Dev &d, u32 K0, u32 *w) {
+    u32 fire = 0, force = 0;
+    if (w[RA_STOP]) w[RA_KIND] = 2;
+    else if (w[RA_HOLD]) {
+        const State *P = &d.ctrl->state[(K0 - 1) & 1]; // how the last run ended: one that ran out of launches goes on with what it had left
+        if (!P->done) { fire = P->allow_fire; force = fire ? OCRGPU_STEP_FORCE_LEVEL : 0u; if (!run_view(d, K0 - 1).over) w[RA_SHORT] += 1; }
+        w[RA_KIND] = 0;
+    } else { fire = 1; force = OCRGPU_STEP_FORCE_LEVEL; w[RA_KIND] = 1; w[RA_ACT] = 0; w[RA_ACT + 1] = 0; }
+    begin_run(d, K0, fire, force);
+}
+__global__ void k_begin_auto(Dev d, u32 K0, u32 *w) { begin_auto(d, K0, w); }
+// End of a run whose last launch was K: fold the run state back into the between-runs view; if the record
+// log is fully consumed, rewind it (keeps q_cap small).
 __device__ __forceinline__ void end_of_run(const Dev &d, u32 K) {
     Ctrl *c = d.ctrl;
     const State P = c->state[K & 1];
@@ -2479,7 +2480,7 @@ __device__ __forceinline__ u64 *peer_arrival(char *base, u32 src) { return (u64 
 // words[1024], which is sticky: nothing is waited for or applied after it, and the host call fails).  The LAST workgroup to
 // finish does the round's exchange_finish, and for rounds queued ahead of the host (`ra_on`) takes the host loop's decisions
 // and starts the next round's run (begin_auto) -- wait, apply, finish and begin in ONE launch.
-#define PIN_RA 33052u // pin[PIN_RA..+4) = {RA_STOP_AT, RA_LEVELS, RA_HOLD, rounds applied} after each round queued ahead
+#define PIN_RA 33052u // pin[PIN_RA..+6) = {RA_STOP_AT, RA_LEVELS, RA_HOLD, rounds applied, Ctrl.noop_steps, RA_SHORT} after each round queued ahead
 __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec *recs, u32 db_floor, u32 K, u32 *pin, u32 *words,
                                      char *win, u64 round, u64 limit, u32 ra_on, u32 no_cascade, u32 next_K0) {
     const u32 per = gridDim.x / n_src; // workgroups per source: the grid is n_src * per, whatever the regions' capacity
@@ -2538,6 +2539,7 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
     const u32 round_no = ra[RA_ROUND]; ra[RA_ROUND] = round_no + 1;
     if (ra[RA_STOP] && !ra[RA_STOP_AT]) ra[RA_STOP_AT] = round_no + 1;
     pin[PIN_RA + 1] = ra[RA_LEVELS]; pin[PIN_RA + 2] = ra[RA_BEHIND] ? 0xBAD0BAD0u : ra[RA_HOLD]; pin[PIN_RA + 3] = round_no + 1; // (stores only: nothing is read back over PCIe)
+    pin[PIN_RA + 4] = __hip_atomic_load(&d.ctrl->noop_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pin[PIN_RA + 5] = ra[RA_SHORT];
     pin[PIN_RA] = ra[RA_STOP_AT]; // 0 = still running; else 1 + the round that ended the run
     if (next_K0) begin_auto(d, next_K0, ra);
 }
@@ -2952,7 +2954,7 @@ struct ocrgpu_engine {
     void *comm; int comm_rank, comm_nranks; SendRec *recv_buf; u64 recv_cap_records;
     // peer windows (ocrgpu_peer_*): my window, the device table of everybody's, what was opened from other processes, the round
     // counter every partition advances together, the wait limit in wall-clock ticks; hdr_fresh: the step just queued wrote the headers
-    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; u32 peer_fence_wave; bool peer_on, hdr_fresh, ahead_timed, end_pending, poisoned /* a peer wait gave up: the level may be partly applied */; hipEvent_t ra_ev[2];
+    char *peer_win; size_t peer_win_bytes; char **peer_base_dev; std::vector<void *> peer_opened; u32 *peer_cnt; u64 peer_round, peer_limit; u32 peer_fence_wave; bool peer_on, hdr_fresh, ahead_timed, end_pending, poisoned /* a peer wait gave up: the level may be partly applied */; hipEvent_t ra_ev[2]; u32 ra_launches, ra_noop_seen, ra_short_seen, ra_rounds_seen, ra_cool; // rounds queued ahead: this engine's step launches per round, sized by what the device reports
     u64 *wp; u64 wp_cap, wp_head, wp_tail; // workpile: ring of guids in HBM, indices kept by the (single) caller side
     // reclaimed capacity (ocrgpu_reclaim, ocrgpu_db_destroy): device tables, host mirrors of the free-stack heights and of the
     // held list's length, a grow-on-demand temporary for the log compaction; mut_epoch moves whenever indices change hands
@@ -3058,7 +3060,7 @@ extern "C" int ocrgpu_init(ocrgpu_engine_t **out, int device, const ocrgpu_confi
     ocrgpu_engine *e = new ocrgpu_engine();
     e->device = device; e->stream = 0; e->own_stream = nullptr; e->cfg = *cfg; e->err_seen = 0;
     e->comm = nullptr; e->comm_rank = 0; e->comm_nranks = 0; e->recv_buf = nullptr; e->recv_cap_records = 0;
-    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_fence_wave = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false; e->poisoned = false; e->ra_ev[0] = e->ra_ev[1] = nullptr;
+    e->peer_win = nullptr; e->peer_win_bytes = 0; e->peer_base_dev = nullptr; e->peer_cnt = nullptr; e->peer_round = 0; e->peer_limit = 0; e->peer_fence_wave = 0; e->peer_on = false; e->hdr_fresh = false; e->ahead_timed = false; e->end_pending = false; e->poisoned = false; e->ra_ev[0] = e->ra_ev[1] = nullptr; e->ra_launches = 0; e->ra_noop_seen = e->ra_short_seen = e->ra_rounds_seen = e->ra_cool = 0;
     e->wp = nullptr; e->wp_cap = 0; e->wp_head = e->wp_tail = 0;
     memset(&e->rc, 0, sizeof e->rc); e->n_free_edt = e->n_free_evt = e->n_free_db = e->n_held = 0; e->mut_epoch = 0; e->recl_tmp = nullptr; e->recl_tmp_cap = 0;
     e->n_edt = e->n_evt = e->n_db = 0; e->n_slots = 0; e->n_script = 0; e->counter = 1; e->edges_upper = 0;
@@ -4321,8 +4323,9 @@ static int run_ahead_round(ocrgpu_engine **g, u32 n, u32 n_launch, u32 no_cascad
         u32 K = e->launch_index + 1; // (no wrap reset inside a run: the previous round's apply has already begun this K)
         if (first) k_begin_auto<<<1, 1, 0, e->stream>>>(d, K, e->peer_cnt); // (afterwards the last workgroup of a round's apply begins the next round)
         const u32 grid = e->step_grid > MAX_GRID ? MAX_GRID : (e->step_grid ? e->step_grid : 256u);
-        for (u32 k = 0; k < n_launch; ++k, ++K) launch_step(e, grid, K);
-        e->launches_total += n_launch; e->launch_index = K - 1;
+        const u32 nl = e->ra_launches ? e->ra_launches : n_launch;
+        for (u32 k = 0; k < nl; ++k, ++K) launch_step(e, grid, K);
+        e->launches_total += nl; e->launch_index = K - 1;
         e->end_pending = true; // (k_end and the headers: in the push kernel)
         HIPCHK(hipGetLastError());
     }
@@ -4342,6 +4345,13 @@ static int resolve_run_ahead(ocrgpu_engine **g, u32 n, u32 flags, u64 *levels_ou
         if (e->d.n_loc < 2) FAIL(OCRGPU_EINVAL, "rounds are queued ahead for partitioned engines only");
         for (int k = 0; k < 2; ++k) if (!e->ra_ev[k]) HIPCHK(hipEventCreateWithFlags(&e->ra_ev[k], hipEventDisableTiming));
         e->pinned_done[PIN_RA] = e->pinned_done[PIN_RA + 1] = e->pinned_done[PIN_RA + 2] = e->pinned_done[PIN_RA + 3] = 0;
+        e->pinned_done[PIN_RA + 4] = e->pinned_done[PIN_RA + 5] = 0;
+        HIPCHK(hipMemsetAsync(&e->d.ctrl->noop_steps, 0, 4, e->stream));
+        // A round's step gets 3 launches to begin with (arrivals, what they set off, the level); a DAG whose arrivals set nothing off
+        // (EDT -> EDT dependences: configs 2-5) needs one, and every launch with nothing to do is 4.5 us in every round.  The device
+        // counts such launches and the rounds whose step ran out (it goes on in the next round: exact either way), and the budget
+        // follows: down when every round had a launch to spare and none ran out, up when a quarter of them ran out.
+        e->ra_launches = (nl || no_cascade) ? 0u : n_launch; e->ra_noop_seen = e->ra_short_seen = e->ra_rounds_seen = 0; e->ra_cool = 0;
         k_ra_init<<<1, 1, 0, e->stream>>>(e->peer_cnt);
     }
     bool stop = false;
@@ -4357,6 +4367,17 @@ static int resolve_run_ahead(ocrgpu_engine **g, u32 n, u32 flags, u64 *levels_ou
             // until the next look.  The run ends after the batch that follows the stopping one, everywhere.
             const u32 at = g[i]->pinned_done[PIN_RA];
             if ((at && (u64)(at - 1) < batch * (u64)ahead) || g[i]->pinned_done[PIN_PEER_LATE]) stop = true;
+            ocrgpu_engine *e = g[i];
+            if (e->ra_launches) { // (what the words say may be a few rounds newer than the batch waited for: only differences are used)
+                const u32 rounds = e->pinned_done[PIN_RA + 3], noop = e->pinned_done[PIN_RA + 4], shrt = e->pinned_done[PIN_RA + 5];
+                const u32 dr = rounds - e->ra_rounds_seen, dn = noop - e->ra_noop_seen, ds = shrt - e->ra_short_seen;
+                if (dr >= ahead / 2u) {
+                    if (4u * ds > dr) { if (e->ra_launches < 3u) e->ra_launches++; e->ra_cool = 3; }
+                    else if (e->ra_cool) e->ra_cool--;
+                    else if (ds == 0 && dn >= dr && e->ra_launches > 1u) e->ra_launches--;
+                    e->ra_rounds_seen = rounds; e->ra_noop_seen = noop; e->ra_short_seen = shrt;
+                }
+            }
         }
     }
     for (u32 i = 0; i < n; ++i) { HIPCHK(hipSetDevice(g[i]->device)); HIPCHK(hipStreamSynchronize(g[i]->stream)); }
