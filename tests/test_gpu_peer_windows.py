@@ -285,3 +285,28 @@ def test_processes_sharing_one_gpu_windows_over_ipc(world, ahead, monkeypatch):
         assert sum(err) == 0
         assert levels == n // width + 1
         assert np.array_equal(lv, ref.level[ids]) and np.array_equal(val, ref.val[ids])
+
+
+def test_rounds_queued_ahead_size_their_launch_budget(monkeypatch):
+    """an EDT -> EDT DAG needs ONE step launch per round (its arrivals set nothing off); the loop starts every round with three and
+    follows what the device reports -- launches with nothing to do, rounds whose step ran out -- down to one.  Same record either way."""
+    s = layered_dag(400_000, 2_000)          # 200 levels: enough batches of 8 rounds for the budget to settle
+    want = O.run_restatement(s)
+    launches = {}
+    for fixed in ("3", None):
+        if fixed:
+            monkeypatch.setenv("OCRGPU_RX_LAUNCHES", fixed)
+        else:
+            monkeypatch.delenv("OCRGPU_RX_LAUNCHES", raising=False)
+        parts = D.build_lockstep([D.Partition(s, r, 2) for r in range(2)])
+        D.connect_peer_windows(parts)
+        before = [int(p.eng.stats().launches) for p in parts]
+        D.resolve_lockstep_c(parts)
+        launches[fixed] = sum(int(p.eng.stats().launches) - b for p, b in zip(parts, before))
+        res = D.gather_result_lockstep(s, parts)
+        errs = [list(p.eng.stats().err) for p in parts]
+        for p in parts:
+            p.eng.close()
+        assert all(sum(e) == 0 for e in errs), errs
+        assert res.diff(want) == []
+    assert launches[None] < 0.6 * launches["3"], launches
