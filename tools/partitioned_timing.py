@@ -5,6 +5,7 @@
 
     python tools/partitioned_timing.py [spec=choleskytiles:256] [world=8]
     python tools/partitioned_timing.py lockable:200000:10000:4096 4        # Lockable datablocks arbitrated by their owners
+    python tools/partitioned_timing.py stencil:1024:10 8                   # config 4: block-partitioned 2 x 4 (OCRGPU_STENCIL_BLOCKS=0: by GUID hash)
 """
 import json
 import os
@@ -29,6 +30,10 @@ def main():
     kw = dict(send_cap=1 << 21, proxy_cap=1_500_000) if spec.startswith("choleskytiles:") and int(spec.split(":")[1]) >= 128 else {}
     if lockable:
         kw["flags"] = F_LOCKABLE_DB
+    if spec.startswith("stencil:") and os.environ.get("OCRGPU_STENCIL_BLOCKS", "1") != "0":   # config 4's placement: blocks of tiles, only halo edges cross
+        G, steps = (int(x) for x in spec.split(":")[1:3])
+        kw["owner_edt"] = D.stencil_block_owner(G, steps, world)
+        kw["send_cap"] = max(1 << 16, 1 << int(G * G // world).bit_length())   # the start event's fan-out reaches every tile of step 0; after it a round carries one level's halo
     parts = D.build_lockstep([D.Partition(s, r, world, **kw) for r in range(world)])
     D.connect_peer_windows(parts)
     for p in parts:
