@@ -360,6 +360,8 @@ int ocrgpu_exchange_local(ocrgpu_engine_t **engines, uint32_t n, uint64_t *activ
  * out of launches (OCRGPU_RX_LAUNCHES), idle after the end -- is decided on the device from the exchanged header sums, alike on
  * every partition.  A NO_CASCADE run in which a partition falls a level behind the others is stopped with OCRGPU_EINVAL rather
  * than mislabelled (the host-driven loop catches such a step up with polls instead).
+ * So is a NO_CASCADE run in which something that ARRIVED set off records for other partitions (an event whose waiters live elsewhere:
+ * the DAG is outside the flag's class, and the records would reach them a round late).
  * OCRGPU_DIST_TIMING=1 in the environment: location 0 prints where a level's wall time went (host-driven loop). */
 #define OCRGPU_RX_NO_CASCADE 1u
 /* OCRGPU_RX_TIME_STEPS (engines made with OCRGPU_F_TIMING): HIP events around every level's k_step launches, summed into

@@ -40,7 +40,7 @@ typedef int32_t s32;
 // device-side layout
 // ------------------------------------------------------------------------------------------------
 enum { ST_ABSENT = 0, ST_LIVE = 1, ST_SAT = 2, ST_DESTROYED = 3 };
-enum { MODE_EVENTS = 0, MODE_FIRE = 1 };
+enum { MODE_EVENTS = 0, MODE_FIRE = 1, MODE_EARLY = 256 /* Step.mode only: queued records are applied in a run that is still to fire its level -- what they send reaches the others a round late unless a settle round follows (Ctrl.nc_sends) */ };
 enum { ERR_DOUBLE_SLOT = 0, ERR_LATE_WAITER = 1, ERR_STICKY_RESAT = 2, ERR_DEAD_EVENT = 3, ERR_BAD_OP = 4,
        ERR_Q_OVERFLOW = 5, ERR_LEVEL_OVERFLOW = 6 };
 #define RF_DST_EDT 1u   // record / waiter destination is an EDT pre-slot
@@ -149,7 +149,7 @@ struct alignas(128) State {
 struct alignas(128) Cnt { u32 v; u32 pad[31]; };
 struct alignas(128) Ctrl {
     // between runs ("absolute" view, used by the API kernels and by k_begin / k_end)
-    u32 level, r_end, q_begin, async_block /* objects / dependences k_async does not take (see there) */, n_levels, b_begin, b_end, max_row /* longest waiter row (seal) */, noop_steps /* k_step launches that found nothing to do (rounds queued ahead size their launch budget by it) */, pad1[23];
+    u32 level, r_end, q_begin, async_block /* objects / dependences k_async does not take (see there) */, n_levels, b_begin, b_end, max_row /* longest waiter row (seal) */, noop_steps /* k_step launches that found nothing to do (rounds queued ahead size their launch budget by it) */, nc_sends /* a level fired with records already queued for other partitions: what arrived set them off (OCRGPU_RX_NO_CASCADE's contract is that nothing does) */, pad1[22];
     u32 r_tail; u32 pad2[31];   // atomics (own cache lines)
     u32 q_tail; u32 pad3[31];
     u32 log_tail; u32 rdst_tail; u32 chan_count, chan_wait_used, chan_sat_used;
@@ -860,7 +860,7 @@ __device__ void fan_out(const Dev &d, const Step &S, Seg *seg, u32 nseg, u32 tot
         if (__ballot(is_latch)) latch_issue(d, is_latch, dst, slot, l_lead, l_old, l_delta);
         if (act) {
             if (flags & RF_DST_EDT) ready = edt_slot_satisfy<NANNY, LOCKABLE != 0>(d, S, dst, slot, payload, flags);
-            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote<TILES == 0 && LOCKABLE != 2, TILES == 2 || LOCKABLE == 2>(d, rd.guid, rd.slot, rd.flags, payload); }
+            else if (flags & RF_REMOTE) { RemoteDst rd = d.rdst[dst]; emit_remote<TILES == 0 && LOCKABLE != 2, TILES == 2 || LOCKABLE == 2>(d, rd.guid, rd.slot, rd.flags, payload); if (LOCKABLE != 2 && (S.mode & MODE_EARLY)) d.ctrl->nc_sends = 1u; } // (Lockable engines with partitions never run without settle rounds)
         }
         // statistics are wave totals (one ballot each), so the epilogue needs no cross-lane reduction
         n_edt_sat += __popcll(__ballot(act && (flags & RF_DST_EDT))); n_evt_sat += __popcll(__ballot(to_evt));
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(BLK) void k_step(Dev d, u32 K) {
     }
     if (N.done) { if (blockIdx.x == 0 && threadIdx.x == 0 && !owed) atomicAdd(&c->noop_steps, 1u); return; } // (a launch that only notices the end)
     Step S;
-    S.mode = N.mode; S.r_begin = N.r_begin; S.r_end = N.r_end; S.q_begin = N.q_begin; S.q_end = N.q_end;
+    S.mode = N.mode | ((LOCKABLE != 2 && N.mode == MODE_EVENTS && N.allow_fire != 0u && d.n_loc > 1) ? MODE_EARLY : 0u); S.r_begin = N.r_begin; S.r_end = N.r_end; S.q_begin = N.q_begin; S.q_end = N.q_end;
     S.r_base = r_total; S.q_base = q_total; S.cnt_r = &c->cnt_r[K % 3].v; S.cnt_q = &c->cnt_q[K % 3].v;
     u64 n_edt_sat = 0, n_evt_sat = 0, n_fired = 0;
     if (blockIdx.x >= part) return; // workgroups beyond the work leave at once
@@ -2468,6 +2468,7 @@ __device__ void exchange_finish(const Dev &d, u32 K, u32 n_src, u64 stride, cons
     const Ctrl *c = d.ctrl;
     if (t < 32) pin[t] = t == 6 ? (run_view(d, K).over ? 1u : 0u) : reinterpret_cast<const u32 *>(&c->state[K & 1])[t]; // word 6 = State.done
     if (t < 8) pin[33020 + t] = __hip_atomic_load(&c->err[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (other workgroups' atomics of this launch)
+    if (t == 0) pin[33058] = c->nc_sends;
 }
 // workgroups of the push kernel per destination: 16 for 2 partitions, 8 for 4, 4 from 8 on (measured with 2 / 4 / 8 partitions on one
 // GPU: every workgroup ends in a system-scope fence, and 128 of those cost more than the parallel copy gains)
@@ -2529,6 +2530,7 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
     // before the exchange; rounds queued ahead cannot, and stop with an error instead of mislabelling.
     const u32 behind = (u32)(sum[3] >> 40);
     if (!late && kind == 1u && no_cascade && behind != 0u && behind != n_src) { ra[RA_STOP] = 1; ra[RA_BEHIND] = 1; }
+    if (!late && no_cascade && d.ctrl->nc_sends) { ra[RA_STOP] = 1; ra[RA_BEHIND] = 2; } // arrivals set off records: they would be a round late (this run is not in NO_CASCADE's class)
     if (late) ra[RA_STOP] = 1;
     else if (kind != 2u) {
         u64 act = *reinterpret_cast<u64 *>(&ra[RA_ACT]) + sum[1];
@@ -2538,7 +2540,7 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
     }
     const u32 round_no = ra[RA_ROUND]; ra[RA_ROUND] = round_no + 1;
     if (ra[RA_STOP] && !ra[RA_STOP_AT]) ra[RA_STOP_AT] = round_no + 1;
-    pin[PIN_RA + 1] = ra[RA_LEVELS]; pin[PIN_RA + 2] = ra[RA_BEHIND] ? 0xBAD0BAD0u : ra[RA_HOLD]; pin[PIN_RA + 3] = round_no + 1; // (stores only: nothing is read back over PCIe)
+    pin[PIN_RA + 1] = ra[RA_LEVELS]; pin[PIN_RA + 2] = ra[RA_BEHIND] == 2u ? 0xBAD0BAD1u : ra[RA_BEHIND] ? 0xBAD0BAD0u : ra[RA_HOLD]; pin[PIN_RA + 3] = round_no + 1; // (stores only: nothing is read back over PCIe)
     pin[PIN_RA + 4] = __hip_atomic_load(&d.ctrl->noop_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pin[PIN_RA + 5] = ra[RA_SHORT];
     pin[PIN_RA] = ra[RA_STOP_AT]; // 0 = still running; else 1 + the round that ended the run
     if (next_K0) begin_auto(d, next_K0, ra);
@@ -4387,6 +4389,8 @@ static int resolve_run_ahead(ocrgpu_engine **g, u32 n, u32 flags, u64 *levels_ou
                                                FAIL(OCRGPU_EHIP, "peer windows: %u of %u partitions did not arrive at location %u within the limit (OCRGPU_PEER_TIMEOUT_MS); "
                                                "the run cannot continue", e->pinned_done[PIN_PEER_LATE], e->d.n_loc, e->cfg.location); }
         if (!e->pinned_done[PIN_RA]) FAIL(OCRGPU_EHIP, "rounds queued ahead ended without the stop word at location %u", e->cfg.location);
+        if (e->pinned_done[PIN_RA + 2] == 0xBAD0BAD1u) FAIL(OCRGPU_EINVAL, "OCRGPU_RX_NO_CASCADE: what arrived at location %u set off records for other partitions (an event whose waiters live elsewhere): "
+                                                                            "they would reach them a round late; the run was stopped. Resolve without OCRGPU_RX_NO_CASCADE", e->cfg.location);
         if (e->pinned_done[PIN_RA + 2] == 0xBAD0BAD0u) FAIL(OCRGPU_EINVAL, "OCRGPU_RX_NO_CASCADE: a partition had not fired its level when the others' records of that level arrived "
                                                                             "(its launches went into what the arrivals of the level before set off); the run was stopped. Resolve without "
                                                                             "OCRGPU_RX_NO_CASCADE, or with OCRGPU_RX_NO_AHEAD=1 / a larger OCRGPU_RX_LAUNCHES");
@@ -4400,6 +4404,11 @@ static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags
     double tm[2] = {0, 0}; const bool timing = getenv("OCRGPU_DIST_TIMING") != nullptr;
     int r, fault = 0; const bool timed = (flags & OCRGPU_RX_TIME_STEPS) != 0;
     do { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, nullptr, &fault, timed))) return r; } while (h[2] || h[3]); // what the main program sent settles first
+    for (u32 i = 0; i < n; ++i) { // from here on a level that fires with records already queued for other partitions is noted (Ctrl.nc_sends)
+        HIPCHK(hipSetDevice(g[i]->device));
+        HIPCHK(hipMemsetAsync(&g[i]->d.ctrl->nc_sends, 0, 4, g[i]->stream));
+        g[i]->pinned_done[33058] = 0;
+    }
     bool all_peer = g[0]->d.n_loc > 1;
     for (u32 i = 0; i < n; ++i) all_peer = all_peer && g[i]->peer_on;
     bool any_lockable = false;
@@ -4413,6 +4422,9 @@ static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags
         // finished with polls)
         if ((r = group_round(g, n, rccl, 1u, OCRGPU_STEP_FORCE_LEVEL | OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault, timed, (flags & OCRGPU_RX_NO_CASCADE) ? 2u : 3u))) return r;
         u64 act = h[1];
+        if (flags & OCRGPU_RX_NO_CASCADE) for (u32 i = 0; i < n; ++i) if (g[i]->pinned_done[33058])
+            FAIL(OCRGPU_EINVAL, "OCRGPU_RX_NO_CASCADE: what arrived at location %u set off records for other partitions (an event whose waiters live elsewhere): "
+                                "they would reach them a round late; the run was stopped. Resolve without OCRGPU_RX_NO_CASCADE", g[i]->cfg.location);
         if (!(flags & OCRGPU_RX_NO_CASCADE) || h[3])
             while (h[2] || h[3]) { if ((r = group_round(g, n, rccl, 0u, OCRGPU_STEP_WRITE_HEADERS, h, timing ? tm : nullptr, &fault, timed))) return r; act += h[1]; }
         if (act == 0) break; // nobody fired or sent anything: the probe level is dropped below

@@ -310,3 +310,30 @@ def test_rounds_queued_ahead_size_their_launch_budget(monkeypatch):
         assert all(sum(e) == 0 for e in errs), errs
         assert res.diff(want) == []
     assert launches[None] < 0.6 * launches["3"], launches
+
+
+@pytest.mark.parametrize("host_driven", [False, True])
+def test_no_cascade_outside_its_class_is_refused_not_mislabelled(host_driven, monkeypatch):
+    """OCRGPU_RX_NO_CASCADE is the caller's promise that nothing that ARRIVES sets off records for other partitions.  The tiled
+    Cholesky breaks it at its tail when the sink latch and the sink EDT live on different partitions (the last task's output event
+    -> latch -> sink EDT: an event whose waiter lives elsewhere): the sink would fire a level late.  The engine notices records sent
+    while a round that is still to fire its level applies what arrived, and stops: exact or refused, never silently wrong."""
+    from ocr_amd.opstream import cholesky_dag
+    if host_driven:
+        monkeypatch.setenv("OCRGPU_RX_NO_AHEAD", "1")
+    refused = []
+    for T, world in ((8, 2), (16, 2), (16, 3), (24, 2), (32, 3), (32, 4), (48, 2)):
+        s = cholesky_dag(T)
+        parts = D.build_lockstep([D.Partition(s, r, world) for r in range(world)])
+        D.connect_peer_windows(parts)
+        try:
+            D.resolve_lockstep_c(parts, no_cascade=True)
+        except E.OcrGpuError as ex:
+            assert "set off records for other partitions" in str(ex)
+            refused.append((T, world))
+        else:
+            res = D.gather_result_lockstep(s, parts)
+            assert res.diff(O.run_restatement(s)) == [], (T, world)
+        for p in parts:
+            p.eng.close()
+    assert (16, 2) in refused and (8, 2) not in refused, refused
