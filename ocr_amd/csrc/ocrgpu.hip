@@ -2295,12 +2295,13 @@ __device__ __forceinline__ u32 wave_reserve_one(u32 *counter) {
     return __shfl(base, leader) + (u32)__popcll(m & ((1ull << lane) - 1ull));
 }
 // the tile behind a head slot -> tiles[idx]; returns the home guid the record names
-__device__ __forceinline__ u64 tile_from_record(const Dev &d, const SendRec *head, u32 idx) {
+__device__ __forceinline__ u64 tile_from_record(const Dev &d, const SendRec *head, u32 idx, u32 first = 0u /* continuation slots below this one are copied by their own lanes (k_exchange_apply_hdr) */) {
     u64 *t = d.ctrl->tiles + OCROPS_TILE_WORDS * (size_t)idx;
     u64 home = 0;
 #pragma unroll 11 // (one lane copies the 22 continuation slots of its record: eleven 32-byte loads in flight at a time, not two -- the apply of a
                   // level of tile records was a chain of eleven round trips per record)
     for (u32 k = 0; k + 1 < TILE_REC_SLOTS; ++k) {
+        if (k < first) continue;
         const SendRec c = head[1 + k];
         const u64 w[3] = {c.guid, c.value, c.tag};
 #pragma unroll
@@ -2310,14 +2311,17 @@ __device__ __forceinline__ u64 tile_from_record(const Dev &d, const SendRec *hea
 }
 __device__ __forceinline__ u64 tile_record_home(const SendRec *head) { return head[1 + OCROPS_TILE_WORDS / 3].value; } // word 64 = slot 21, second field
 // `avail` = slots from this one to the end of what arrived in its region (a head's continuation slots must lie within it)
-__device__ void apply_record(const Dev &d, const SendRec *rp, u32 avail, u32 db_floor) {
+// `tile_dst` (k_exchange_apply_hdr): the head of a tile record only says where its tile goes (*tile_dst = index + 1) and copies the
+// continuation slots from `in_chunk` on; the slots in front of that are copied by the lanes that hold them (one lane per slot there)
+__device__ void apply_record(const Dev &d, const SendRec *rp, u32 avail, u32 db_floor, u32 *tile_dst = nullptr, u32 in_chunk = 0u) {
     const SendRec r = *rp;
     if (r.flags & XF_CONT) return; // part of the head in front of it
     if ((r.flags & XF_HAS_TILE) && (avail < TILE_REC_SLOTS || !d.ctrl->tiles)) { bad_op(d); return; }
     if (r.flags & XF_TILE_WB) { // a copy of one of OUR datablocks was updated elsewhere: its contents come home
         const u64 v = (OCRGPU_GUID_LOCATION(r.guid) == d.location && OCRGPU_GUID_KIND(r.guid) == OCRGPU_KIND_DB && (r.flags & XF_HAS_TILE)) ? gtab_get(d, r.guid) : 0;
         if (!v || v - 1 >= d.max_db) { bad_op(d); return; }
-        tile_from_record(d, rp, (u32)(v - 1));
+        if (tile_dst) *tile_dst = (u32)v;
+        tile_from_record(d, rp, (u32)(v - 1), tile_dst ? in_chunk : 0u);
         return;
     }
     if (r.flags & (XF_ACQ | XF_REL | XF_GRANT)) { // Lockable datablocks: this partition arbitrates the datablock named (ACQ / REL), or asked for one (GRANT)
@@ -2356,14 +2360,14 @@ __device__ void apply_record(const Dev &d, const SendRec *rp, u32 avail, u32 db_
     if (home && OCRGPU_GUID_LOCATION(home) == d.location) { // one of OUR datablocks comes back (a tile: with what was done to it elsewhere): no copy, the original
         const u64 v = gtab_get(d, home);
         if (!v || v - 1 >= d.max_db) { bad_op(d); return; }
-        if (r.flags & XF_HAS_TILE) tile_from_record(d, rp, (u32)(v - 1));
+        if (r.flags & XF_HAS_TILE) { if (tile_dst) *tile_dst = (u32)v; tile_from_record(d, rp, (u32)(v - 1), tile_dst ? in_chunk : 0u); }
         pay = (u32)v;
     } else if ((r.flags & XF_HAS_DB) && !(r.flags & XF_LAZYREG)) { // only a record that carries a datablock takes a proxy entry
         const u32 pi = wave_reserve_one(&d.ctrl->proxy_used);
         if ((u64)pi + 1 + db_floor > d.max_db) { atomicAdd(&d.ctrl->err[ERR_Q_OVERFLOW], 1u); return; }
         const u32 proxy = d.max_db - 1u - pi;
         d.db[proxy] = make_ulonglong2(r.value, r.tag); pay = proxy + 1;
-        if (r.flags & XF_HAS_TILE) tile_from_record(d, rp, proxy);
+        if (r.flags & XF_HAS_TILE) { if (tile_dst) *tile_dst = proxy + 1u; tile_from_record(d, rp, proxy, tile_dst ? in_chunk : 0u); }
         if (d.ctrl->db_home) d.ctrl->db_home[proxy] = home; // (0: the output datablock of an EDT -- contended only where a copy lives)
     }
     u32 didx, dslot, dflag;
@@ -2505,7 +2509,36 @@ __global__ void k_exchange_apply_hdr(Dev d, u32 n_src, u64 stride, const SendRec
     if (ok) {
         u64 cnt = recs[(u64)s * stride + (stride - 1)].guid; // header word 0
         if (cnt > stride - 1) cnt = stride - 1;
-        for (u64 k = part * (u64)blockDim.x + threadIdx.x; k < cnt; k += per * (u64)blockDim.x) apply_record(d, recs + ((u64)s * stride + k), (u32)(cnt - k), db_floor);
+        if (!d.ctrl->tiles) {
+            for (u64 k = part * (u64)blockDim.x + threadIdx.x; k < cnt; k += per * (u64)blockDim.x) apply_record(d, recs + ((u64)s * stride + k), (u32)(cnt - k), db_floor);
+        } else {
+            // Tile records (23 slots): one lane per slot, and the lane of a head used to copy all 22 continuation slots itself -- 704 bytes
+            // read by one lane while 22 sat idle; a level of 40 000 tile records took the apply to a millisecond.  Now the head says where
+            // its tile goes and every continuation slot of its 256-slot chunk is copied by its own lane (coalesced); the head keeps only
+            // the slots that lie past the end of the chunk.
+            __shared__ u32 tile_of[256];
+            for (u64 base = part * (u64)blockDim.x; base < cnt; base += per * (u64)blockDim.x) { // (workgroup-uniform: barriers inside)
+                const u64 k = base + threadIdx.x;
+                const SendRec *rp = recs + ((u64)s * stride + k);
+                u32 td = 0;
+                if (k < cnt) apply_record(d, rp, (u32)(cnt - k), db_floor, &td, 255u - threadIdx.x);
+                tile_of[threadIdx.x] = td;
+                __syncthreads();
+                if (k < cnt) {
+                    const SendRec c = *rp;
+                    if ((c.flags & XF_CONT) && c.slot + 1u < TILE_REC_SLOTS && threadIdx.x > c.slot) {
+                        const u32 t = tile_of[threadIdx.x - 1u - c.slot];
+                        if (t) {
+                            u64 *tw = d.ctrl->tiles + OCROPS_TILE_WORDS * (size_t)(t - 1u);
+                            const u64 w[3] = {c.guid, c.value, c.tag};
+#pragma unroll
+                            for (u32 j = 0; j < 3; ++j) { const u32 i = 3u * c.slot + j; if (i < OCROPS_TILE_WORDS) tw[i] = w[j]; }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
     }
     // (every wave waits for its own stores -- the explicit s_waitcnt: a workgroup-scope release compiles to no vector-memory wait on
     // this target -- the barrier joins them, ONE lane releases for the workgroup at device scope: a release is cumulative over what
