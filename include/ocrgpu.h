@@ -111,8 +111,8 @@ typedef struct {
                                  * takes 2 slots of its send region (the second names the original), an EDT whose next
                                  * datablock -- in ascending guid order, one order everywhere -- is a copy asks the owner with
                                  * a record and goes on when the grant arrives, the level that fires it sends the releases.
-                                 * Grants and releases are records that set off records: not with OCRGPU_RX_NO_CASCADE, rounds
-                                 * are driven by the host (never queued ahead), ocrgpu_snapshot is refused.  The output
+                                 * Grants and releases are records that set off records: not with OCRGPU_RX_NO_CASCADE;
+                                 * ocrgpu_snapshot is refused.  The output
                                  * datablock of an EDT that travels to another partition is a private copy there (arbitrated
                                  * where the copy lives).                                                                 */
 

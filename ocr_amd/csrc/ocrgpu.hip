@@ -4125,8 +4125,12 @@ static int xchg_land(ocrgpu_engine *e, const SendRec *recs, bool windows, u64 *o
     int r = xchg_words(e); if (r) return r;
     // the header sums, the state the last step ended in and the error counters ride on the same synchronisation (step_ahead does not poll)
     k_exchange_apply_hdr<<<d.n_loc * per, 256, 0, e->stream>>>(d, d.n_loc, d.send_cap, recs, e->n_db, e->launch_index, e->pinned_dev, e->peer_cnt,
-                                                             windows ? e->peer_win : nullptr, e->peer_round, e->peer_limit, ahead ? 1u : 0u, no_cascade, next_K0);
-    remote_releases(e); // (Lockable datablocks: never with rounds queued ahead -- the next run would have begun before these)
+                                                             windows ? e->peer_win : nullptr, e->peer_round, e->peer_limit, ahead ? 1u : 0u, no_cascade,
+                                                             (e->dbl && d.n_loc > 1) ? 0u : next_K0);
+    remote_releases(e);
+    // (Lockable engines: the releases a round brought in run in the launch above, behind the apply, and queue records -- the next round's
+    // run begins behind them, not in the apply's last workgroup)
+    if (next_K0 && e->dbl && d.n_loc > 1) k_begin_auto<<<1, 1, 0, e->stream>>>(d, next_K0, e->peer_cnt);
     HIPCHK(hipGetLastError());
     if (ahead) return 0; // rounds queued ahead: the caller synchronises once per batch
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -4445,9 +4449,9 @@ static int resolve_exchange_group(ocrgpu_engine **g, u32 n, bool rccl, u32 flags
     bool all_peer = g[0]->d.n_loc > 1;
     for (u32 i = 0; i < n; ++i) all_peer = all_peer && g[i]->peer_on;
     bool any_lockable = false;
-    for (u32 i = 0; i < n; ++i) any_lockable = any_lockable || g[i]->dbl != nullptr; // (their releases run behind the apply: the host drives every round)
+    for (u32 i = 0; i < n; ++i) any_lockable = any_lockable || g[i]->dbl != nullptr; // (their releases run behind the apply, and the next round's run begins behind those: xchg_land; OCRGPU_RX_LOCKABLE_HOST=1 keeps the host-driven loop)
     if (any_lockable && (flags & OCRGPU_RX_NO_CASCADE)) FAIL(OCRGPU_EINVAL, "OCRGPU_RX_NO_CASCADE with Lockable datablocks: grants and releases are records that set off records");
-    const bool queue_ahead = all_peer && !any_lockable && !timed && !timing && !getenv("OCRGPU_RX_POLLED") && !getenv("OCRGPU_RX_NO_AHEAD");
+    const bool queue_ahead = all_peer && (!any_lockable || !getenv("OCRGPU_RX_LOCKABLE_HOST")) && !timed && !timing && !getenv("OCRGPU_RX_POLLED") && !getenv("OCRGPU_RX_NO_AHEAD");
     if (queue_ahead) { if ((r = resolve_run_ahead(g, n, flags, &levels, &fault))) return r; }
     else for (;;) {
         // launches queued for a level: the records that arrived, the level itself (that the run is then over is seen without a
