@@ -4120,6 +4120,7 @@ static int xchg_land(ocrgpu_engine *e, const SendRec *recs, bool windows, u64 *o
     // GPU: 8 x 32 x 8 workgroups of waiting applies filled the chip).  Measured with a stream per partition, 4 partitions 118 -> 108 us
     // per level, 8 partitions 207 -> 161.  OCRGPU_APPLY_BLOCKS overrides.
     u32 per = (d.send_cap + 254u) / 256u, lim = d.n_loc <= 2 ? 32u : (32u / d.n_loc < 4u ? 4u : 32u / d.n_loc);
+    if (e->tiles) lim *= 2u; // (records of 23 slots, one lane per slot: T = 256 on 2 partitions 178 -> 157 ms, on 8: 466 -> 434; four times as many is worse again)
     { static const char *ab = getenv("OCRGPU_APPLY_BLOCKS"); if (ab && atoi(ab) > 0) lim = (u32)atoi(ab) > 512u ? 512u : (u32)atoi(ab); }
     if (per > lim) per = lim;
     int r = xchg_words(e); if (r) return r;
